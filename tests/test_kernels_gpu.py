@@ -1,0 +1,265 @@
+"""GPU parity of each librvit kernel against a plain torch fp32 CPU computation of the same op
+on the same (bf16-rounded) inputs.  Tolerances are bf16-output tolerances: the kernels accumulate
+in fp32, so the only error sources are the final bf16 rounding (rel 2^-8) and summation order."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _close(got, ref, rtol, atol, what=""):
+    got = got.float().cpu()
+    ref = ref.float()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = (err > bound).sum().item()
+    assert bad == 0, f"{what}: {bad}/{err.numel()} out of tolerance, max err {err.max().item():.4g}"
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (128, 128, 64), (1000, 768, 200), (77, 11, 128), (64, 1024, 264)])
+def test_gemm_plain(dev, M, N, K, tile):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = _bf(torch.randn(M, K, generator=g))
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    ref = a.float() @ w.float().T
+    out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out, tile=tile)
+    _close(out, ref, 1e-4, 1e-4, "gemm f32 out")
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), outb, tile=tile)
+    _close(outb, ref, 1.0 / 128, 1e-3, "gemm bf16 out")
+
+
+def test_gemm_identity_asymmetric(dev):
+    """A = I with an asymmetric B catches a transposed C write (guide §3)."""
+    from vit_amd import ops
+    n = 128
+    a = _bf(torch.eye(n))
+    w = _bf(torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 100)
+    out = torch.empty(n, n, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out)
+    assert torch.equal(out.cpu(), w.float().T)
+
+
+@pytest.mark.parametrize("act", [None, "relu", "gelu"])
+@pytest.mark.parametrize("res_dtype", [None, torch.float32, torch.bfloat16])
+def test_gemm_epilogue(dev, act, res_dtype):
+    from vit_amd import ops
+    M, N, K = 200, 320, 128
+    g = torch.Generator().manual_seed(5)
+    a = _bf(torch.randn(M, K, generator=g))
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    scale = torch.rand(N, generator=g) + 0.5
+    res = None if res_dtype is None else torch.randn(M, N, generator=g).to(res_dtype)
+    pre = a.float() @ w.float().T * scale + bias
+    ref = pre if res is None else pre + res.float()
+    if act == "relu":
+        ref = torch.relu(ref)
+    elif act == "gelu":
+        ref = F.gelu(ref)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    preact = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev), scale=scale.to(dev),
+             residual=None if res is None else res.to(dev), act=act, preact=preact)
+    _close(out, ref, 1.0 / 128, 2e-3, "epilogue out")
+    _close(preact, pre, 1.0 / 128, 2e-3, "preact")
+
+
+def test_gemm_scalar_tail_and_inplace_residual(dev):
+    from vit_amd import ops
+    M, N, K = 33, 11, 128
+    g = torch.Generator().manual_seed(9)
+    a = _bf(torch.randn(M, K, generator=g))
+    w = _bf(torch.randn(N, K, generator=g) / 8)
+    bias = torch.randn(N, generator=g)
+    out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out, bias=bias.to(dev))
+    _close(out, a.float() @ w.float().T + bias, 1e-4, 1e-4, "N=11")
+    # in-place fp32 residual stream update: x = x + a @ w.T + b
+    N2 = 256
+    w2 = _bf(torch.randn(N2, K, generator=g) / 8)
+    b2 = torch.randn(N2, generator=g)
+    x = torch.randn(M, N2, generator=g)
+    xd = x.to(dev)
+    ops.gemm(a.to(dev), w2.to(dev), xd, bias=b2.to(dev), residual=xd)
+    _close(xd, x + a.float() @ w2.float().T + b2, 1e-4, 1e-4, "in-place residual")
+
+
+def test_gemm_patch_embed_remap(dev):
+    """1x1 patch_embed epilogue: token-major scatter past the cls row + pos_embed add
+    (train_vit.py:149-159)."""
+    from vit_amd import ops
+    B, P, C, E = 5, 49, 512, 256
+    g = torch.Generator().manual_seed(11)
+    feat = _bf(torch.randn(B * P, C, generator=g))
+    w = _bf(torch.randn(E, C, generator=g) / math.sqrt(C))
+    bias = torch.randn(E, generator=g)
+    pos = torch.randn(P + 1, E, generator=g)
+    x = torch.full((B * (P + 1), E), 7.0, dtype=torch.float32, device=dev)
+    posd = pos.to(dev)
+    ops.gemm(feat.to(dev), w.to(dev), x, bias=bias.to(dev), residual=posd[1:], residual_period=P,
+             row_group=P, row_extra=1)
+    ref = (feat.float() @ w.float().T + bias).reshape(B, P, E) + pos[1:]
+    got = x.cpu().reshape(B, P + 1, E)
+    assert torch.all(got[:, 0] == 7.0), "cls rows must be untouched"
+    _close(got[:, 1:], ref, 1e-4, 1e-4, "patch rows")
+
+
+@pytest.mark.parametrize("rows,E", [(37, 256), (1000, 768), (5, 1024), (12, 384), (9, 64)])
+@pytest.mark.parametrize("in_dt", [torch.float32, torch.bfloat16])
+def test_layernorm(dev, rows, E, in_dt):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(rows + E)
+    x = (torch.randn(rows, E, generator=g) * 2 + 0.5).to(in_dt)
+    gam = torch.randn(E, generator=g)
+    bet = torch.randn(E, generator=g)
+    ref = F.layer_norm(x.float(), (E,), gam, bet, 1e-5)
+    out = torch.empty(rows, E, dtype=torch.float32, device=dev)
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+    ops.layernorm(x.to(dev), gam.to(dev), bet.to(dev), out, mean=mean, rstd=rstd)
+    _close(out, ref, 1e-5, 2e-5, "ln f32")
+    _close(mean, x.float().mean(1), 1e-5, 1e-5, "mean")
+    _close(rstd, 1 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5), 1e-5, 1e-5, "rstd")
+    outb = torch.empty(rows, E, dtype=torch.bfloat16, device=dev)
+    ops.layernorm(x.to(dev), gam.to(dev), bet.to(dev), outb)
+    _close(outb, ref, 1.0 / 128, 1e-3, "ln bf16")
+
+
+def test_layernorm_strided_cls_rows(dev):
+    from vit_amd import ops
+    B, S, E = 6, 50, 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, S, E, generator=g)
+    gam, bet = torch.randn(E, generator=g), torch.randn(E, generator=g)
+    xd = x.to(dev)
+    out = torch.empty(B, E, dtype=torch.float32, device=dev)
+    ops.layernorm(xd.view(B, S * E)[:, :E], gam.to(dev), bet.to(dev), out)
+    _close(out, F.layer_norm(x[:, 0], (E,), gam, bet), 1e-5, 2e-5, "cls LN")
+
+
+@pytest.mark.parametrize("B,S,H", [(3, 50, 4), (2, 197, 12), (5, 17, 2), (1, 64, 1), (2, 100, 3), (1, 256, 2),
+                                   (3, 130, 2), (2, 161, 1)])
+def test_attention(dev, B, S, H):
+    from vit_amd import ops
+    E = H * 64
+    g = torch.Generator().manual_seed(B * 100 + S)
+    qkv = _bf(torch.randn(B * S, 3 * E, generator=g) * 1.5)
+    q, k, v = [t.reshape(B, S, H, 64).transpose(1, 2).float() for t in qkv.split(E, dim=1)]
+    sc = q @ k.transpose(-1, -2) / 8.0
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B * S, E)
+    ref_lse = torch.logsumexp(sc, -1)
+    out = torch.zeros(B * S, E, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+    ops.attention(qkv.to(dev), out, B, S, H, lse=lse)
+    # P is rounded to bf16 before PV: abs error ~ 2^-9 * max|v| per row, plus the output rounding
+    _close(out, ref, 1.0 / 64, 2e-2, "attention out")
+    _close(lse, ref_lse, 1e-4, 1e-4, "lse")
+
+
+def test_attention_asymmetric_exact(dev):
+    """Integer-valued data where every product is exact: catches any fragment-layout permutation
+    (one-hot softmax via a huge score gap picks V rows exactly)."""
+    from vit_amd import ops
+    B, S, H = 1, 50, 2
+    E = H * 64
+    q = torch.zeros(B, S, H, 64)
+    k = torch.zeros(B, S, H, 64)
+    v = torch.zeros(B, S, H, 64)
+    perm = torch.randperm(S, generator=torch.Generator().manual_seed(1))
+    for s in range(S):
+        # query s matches key perm[s] only: one-hot in a 50-dim code (dims 0..49), score 64*8=512
+        q[0, s, :, s] = 64.0
+        k[0, perm[s], :, s] = 64.0
+    v[0] = (torch.arange(S * H * 64).reshape(S, H, 64) % 127 - 63).float()
+    qkv = _bf(torch.cat([q.reshape(S, E), k.reshape(S, E), v.reshape(S, E)], dim=1))
+    out = torch.zeros(S, E, dtype=torch.bfloat16, device=dev)
+    ops.attention(qkv.to(dev), out, B, S, H)
+    ref = v[0][perm].reshape(S, E)
+    assert torch.equal(out.float().cpu(), ref), "attention picks wrong V rows/columns"
+
+
+def _conv_ref(x_nhwc, w_ohwi, stride, pad):
+    return F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w_ohwi.float().permute(0, 3, 1, 2), None, stride, pad)
+
+
+@pytest.mark.parametrize("cin,cout,hw,k,stride,pad", [(64, 64, 56, 3, 1, 1), (64, 128, 56, 3, 2, 1),
+                                                      (64, 128, 56, 1, 2, 0), (256, 512, 14, 3, 2, 1),
+                                                      (512, 512, 7, 3, 1, 1), (128, 128, 28, 3, 1, 1)])
+@pytest.mark.parametrize("tile", [0, 3])
+def test_conv_nhwc(dev, cin, cout, hw, k, stride, pad, tile):
+    from vit_amd import ops
+    B = 3
+    g = torch.Generator().manual_seed(cin + cout + hw + k)
+    x = _bf(torch.randn(B, hw, hw, cin, generator=g))
+    w = _bf(torch.randn(cout, k, k, cin, generator=g) / math.sqrt(k * k * cin))
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g)
+    ho = (hw + 2 * pad - k) // stride + 1
+    res = _bf(torch.randn(B, ho, ho, cout, generator=g))
+    ref = _conv_ref(x, w, stride, pad) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    ref = torch.relu(ref + res.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    out = torch.empty(B, ho, ho, cout, dtype=torch.bfloat16, device=dev)
+    ops.conv2d(x.to(dev), w.reshape(cout, -1).to(dev), out, kh=k, kw=k, stride=stride, pad=pad,
+               scale=scale.to(dev), bias=bias.to(dev), residual=res.to(dev), act="relu", tile=tile)
+    _close(out, ref, 1.0 / 128, 3e-3, "conv")
+
+
+def test_stem_conv1_pack_and_pool(dev):
+    """fp32 NCHW -> haloed NHWC4 -> 7x7/2 conv as 7 taps of 8px x 4ch runs -> 3x3/2 max-pool."""
+    from vit_amd import ops
+    B, H = 2, 224
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, 3, H, H, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    xp = torch.zeros(B, H + 6, H + 8, 4, dtype=torch.bfloat16, device=dev)
+    ops.input_pack(x.to(dev), xp, 3, 3)
+    ref_p = torch.zeros(B, H + 6, H + 8, 4)
+    ref_p[:, 3:3 + H, 3:3 + H, :3] = _bf(x).float().permute(0, 2, 3, 1)
+    assert torch.equal(xp.float().cpu(), ref_p), "input pack"
+    wp = torch.zeros(64, 7, 8, 4)
+    wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wp = _bf(wp)
+    y = torch.empty(B, 112, 112, 64, dtype=torch.bfloat16, device=dev)
+    ops.conv2d(xp, wp.reshape(64, 224).to(dev), y, kh=7, kw=1, stride=2, pad=0, seg_len=32, act="relu")
+    ref = torch.relu(F.conv2d(_bf(x).float(), _bf(w).float(), None, 2, 3))
+    _close(y, ref.permute(0, 2, 3, 1), 1.0 / 128, 3e-3, "conv1")
+    p = torch.empty(B, 56, 56, 64, dtype=torch.bfloat16, device=dev)
+    am = torch.empty(B, 56, 56, 64, dtype=torch.uint8, device=dev)
+    ops.maxpool3x3s2(y, p, am)
+    refp = F.max_pool2d(y.float().cpu().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(p.float().cpu(), refp), "maxpool"
+    assert int(am.max()) <= 8
+
+
+def test_embed_cls(dev):
+    from vit_amd import ops
+    B, S, E = 4, 50, 256
+    cls = torch.randn(1, 1, E)
+    pos = torch.randn(1, S, E)
+    x = torch.zeros(B, S, E, device=dev)
+    ops.embed_cls(cls.to(dev), pos.to(dev), x)
+    assert torch.equal(x[:, 0].cpu(), (cls[0, 0] + pos[0, 0]).expand(B, E))
+    assert float(x[:, 1:].abs().sum()) == 0.0
+
+
+def test_errors_are_loud(dev):
+    from vit_amd import ops
+    from vit_amd._lib import RvitError
+    a = torch.zeros(8, 12, dtype=torch.bfloat16, device=dev)   # K=12 not a multiple of 8
+    w = torch.zeros(8, 12, dtype=torch.bfloat16, device=dev)
+    out = torch.zeros(8, 8, dtype=torch.float32, device=dev)
+    with pytest.raises(RvitError):
+        ops.gemm(a, w, out)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a.cpu(), w.cpu(), out.cpu())

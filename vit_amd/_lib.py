@@ -1,0 +1,69 @@
+"""ctypes binding of librvit.so (the C ABI declared in include/rvit.h).
+
+There is exactly one compute path: the HIP library.  If it is missing or a call fails, this
+module raises — there is no CPU or eager-PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librvit.so")
+
+RVIT_BF16, RVIT_F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ABI_VERSION = 1
+
+
+class RvitError(RuntimeError):
+    """A librvit entry point returned a non-zero status."""
+
+
+# name -> argtypes, exactly mirroring include/rvit.h (tests/test_abi.py cross-checks the header)
+SIGNATURES = {
+    "rvit_version": ([], c_int),
+    "rvit_last_error": ([], c_char_p),
+    "rvit_gemm_bf16": ([c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int, c_int,
+                        c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_int,
+                        c_int, c_int, c_void_p], c_int),
+    "rvit_conv2d_fwd_bf16": ([c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p, c_void_p,
+                             c_int, c_int, c_void_p], c_int),
+    "rvit_input_pack_nhwc4": ([c_void_p, c_void_p] + [c_int] * 8 + [c_void_p], c_int),
+    "rvit_maxpool3x3s2_nhwc": ([c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p], c_int),
+    "rvit_embed_cls": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
+    "rvit_layernorm_fwd": ([c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
+                            c_void_p, c_int64, c_int, c_float, c_void_p], c_int),
+    "rvit_attn_fwd": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p],
+                      c_int),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load librvit.so once; raise loudly when it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"librvit.so not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C vit_amd/csrc`. vit_amd has no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = restype
+    ver = lib.rvit_version()
+    if ver != ABI_VERSION:
+        raise ImportError(f"librvit.so ABI version {ver} != expected {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().rvit_last_error()
+        raise RvitError(f"{what} failed with status {status}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,204 @@
+// Multi-head self-attention for short sequences (S <= 256, head_dim 64), forward.
+// Replaces torch scaled_dot_product_attention as called from multi_head_attention_forward
+// (torch functional.py:6569-6570, 6623-6631): softmax(q k^T / sqrt(Dh)) v, no mask, not causal.
+//
+// gfx950 structure: K and V of one (batch, head) are staged once into LDS (K rows XOR-swizzled
+// for conflict-free ds_read_b128, V rows padded to 192 B for conflict-free ds_read_b64_tr_b16);
+// each wave owns a 32-query block: scores are computed TRANSPOSED (S^T = K q^T, 32x32x16 MFMA) so
+// that one lane owns one query column -> the softmax row reduction is a register reduction plus
+// one cross-half shuffle; the exponentiated accumulator tile is fed straight back as the B
+// operand of the PV product (O^T = V^T P^T) with V^T fragments produced by the hardware
+// transposing LDS read.  The whole key range fits in registers (S <= 256), so no online rescale.
+#include "common.h"
+#include "rvit_internal.h"
+
+namespace {
+
+__device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+constexpr int V_PITCH = 192;  // bytes per V row in LDS
+
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  return __builtin_bit_cast(bf16x4, r);
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                       float* __restrict__ lse, int total_pairs, int S, int H,
+                                                       long ldq, long ldo, float scale_log2e, float scale) {
+  constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
+  constexpr int SP = 32 * NKB;
+  constexpr int PAIR_BYTES = SP * (128 + V_PITCH);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int E = H * 64;
+  const int pair0 = blockIdx.x * PAIRS;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  // ---- stage K and V of every pair of this workgroup -------------------------------------------
+#pragma unroll
+  for (int pi = 0; pi < PAIRS; ++pi) {
+    const int pair = pair0 + pi;
+    const bool pv = pair < total_pairs;
+    const int b = pv ? pair / H : 0, h = pv ? pair % H : 0;
+    const bf16* kbase = qkv + (long)b * S * ldq + E + h * 64;
+    const bf16* vbase = kbase + E;
+    char* sK = smem + pi * PAIR_BYTES;
+    char* sV = sK + SP * 128;
+    for (int id = t; id < SP * 8; id += 256) {
+      const int row = id >> 3, c = id & 7;
+      const bool ok = pv && row < S;
+      const uint4 kv = ok ? *reinterpret_cast<const uint4*>(kbase + (long)row * ldq + c * 8) : zero4;
+      const uint4 vv = ok ? *reinterpret_cast<const uint4*>(vbase + (long)row * ldq + c * 8) : zero4;
+      *reinterpret_cast<uint4*>(sK + k_off(row, c)) = kv;
+      *reinterpret_cast<uint4*>(sV + row * V_PITCH + c * 16) = vv;
+    }
+  }
+  __syncthreads();
+
+  const int r32 = lane & 31, h2 = lane >> 5;
+  for (int qi = wave; qi < PAIRS * NKB; qi += 4) {  // wave-uniform
+    const int pi = qi / NKB, qb = qi - pi * NKB;
+    const int pair = pair0 + pi;
+    if (pair >= total_pairs) continue;
+    if (qb * 32 >= S) continue;
+    const int b = pair / H, h = pair - b * H;
+    const char* sK = smem + pi * PAIR_BYTES;
+    const char* sV = sK + SP * 128;
+    const int query = qb * 32 + r32;
+    const bool q_ok = query < S;
+    const bf16* qrow = qkv + ((long)b * S + (q_ok ? query : 0)) * ldq + h * 64;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 u = q_ok ? *reinterpret_cast<const uint4*>(qrow + ks * 16 + h2 * 8) : zero4;
+      qf[ks] = __builtin_bit_cast(bf16x8, u);
+    }
+
+    // S^T[key][query] for all key blocks
+    f32x16 sc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + k_off(kb * 32 + r32, ks * 2 + h2));
+        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        if (key >= S) sc[kb][r] = -INFINITY;
+        mx = fmaxf(mx, sc[kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pe = exp2f((sc[kb][r] - mx) * scale_log2e);
+        sc[kb][r] = pe;
+        sum += pe;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+
+    // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    const int tr_q = (lane >> 2) & 3;
+    const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[kb][8 * s + j];
+        const int key0 = kb * 32 + 16 * s + 4 * h2;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const char* base = sV + (key0 + tr_q) * V_PITCH + (db * 32 + tr_col) * 2;
+          const bf16x4 lo = tr_read(base);
+          const bf16x4 hi = tr_read(base + 8 * V_PITCH);
+          bf16x8 vf;
+          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+          vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[db], 0, 0, 0);
+        }
+      }
+    }
+    const float inv = 1.0f / sum;
+    if (q_ok) {
+      bf16* orow = out + ((long)b * S + query) * ldo + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 w;
+          w.x = pack_bf16x2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
+          w.y = pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g + 4 * h2) = w;
+        }
+      if (lse && h2 == 0) lse[(long)pair * S + query] = mx * scale + logf(sum);
+    }
+  }
+}
+
+template <int NKB>
+int launch_attn_fwd(const bf16* qkv, bf16* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
+                    hipStream_t st) {
+  constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
+  constexpr int LDS = PAIRS * 32 * NKB * (128 + V_PITCH);
+  static bool attr_set = false;
+  if (LDS > 65536 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      rvit_set_error("attn_fwd: cannot raise LDS limit to %d: %s", LDS, hipGetErrorString(e));
+      return RVIT_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int total = B * H;
+  const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
+  hipLaunchKernelGGL((attn_fwd_kernel<NKB>), dim3(grid), dim3(256), LDS, st, qkv, out, lse, total, S, H, ldq, ldo,
+                     scale * 1.44269504088896340736f, scale);
+  RVIT_CHECK_LAUNCH("attn_fwd");
+  return RVIT_OK;
+}
+
+}  // namespace
+
+int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
+                       hipStream_t st) {
+  RVIT_CHECK_ARG(qkv && out, "attn_fwd: null pointer");
+  RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_fwd: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
+  RVIT_CHECK_ARG(ldq >= 3L * H * 64 && (ldq & 7) == 0 && ldo >= (long)H * 64 && (ldo & 3) == 0,
+                 "attn_fwd: bad pitches ldq=%ld ldo=%ld", ldq, ldo);
+  RVIT_CHECK_ARG(rvit_aligned16(qkv) && ((uintptr_t)out & 7) == 0, "attn_fwd: alignment");
+  const bf16* q = (const bf16*)qkv;
+  bf16* o = (bf16*)out;
+  switch ((S + 31) / 32) {
+    case 1: return launch_attn_fwd<1>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+    case 2: return launch_attn_fwd<2>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+    case 3: return launch_attn_fwd<3>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+    case 4: return launch_attn_fwd<4>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+    case 5: return launch_attn_fwd<5>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+    case 6: return launch_attn_fwd<6>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+    case 7: return launch_attn_fwd<7>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+    case 8: return launch_attn_fwd<8>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+  }
+  rvit_set_error("attn_fwd: S=%d unsupported", S);
+  return RVIT_EUNSUPPORTED;
+}
