@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched bf16 inference of the hybrid CNN-stem + ViT radar classifier
+(`cnn_vit_radar.pt` layout: resnet18 stem + E256/H4/L4, BASELINE.json configs[1]) on synthetic
+micro-Doppler-shaped inputs, frames/s aggregated over N GPUs (batch sharded, no data-path
+collective).
+
+  python bench.py --gpus N --steps K --warmup W [--batch B]
+N>1 is launched by torch.distributed.run, one rank per GPU; rank 0 prints ONE JSON line.
+
+A "step" is one forward pass of the hot path (image pack -> stem -> patch embed -> encoder ->
+head) over one batch already resident in HBM.  `roofline` is measured live with HIP events around
+every launch of the dominant kernel (the implicit-GEMM conv); `cpu_baseline` times the torch fp32
+oracle (the reference's own torch.nn arithmetic) on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+R_CFG = dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18")
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md:43
+HBM_PEAK_GBS = 8000.0            # spec, MI355X_MICROARCH.md:36
+FWD_FLOPS_PER_SAMPLE = 3.965e9   # BASELINE.md §2 (R hybrid)
+
+
+def cpu_baseline(sd, seconds=20.0, batch=8):
+    """Oracle (kind='port': same torch.nn calls as the reference, train_vit.py:93-127 + ResNet-18
+    restatement) on the host cores; mirrors the reference's batch-8 loop (infer.py:459-469)."""
+    from oracle.ref_model import CNNViTHybridRef
+    from vit_amd.synth import micro_doppler_batch
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    ref = CNNViTHybridRef(**R_CFG)
+    ref.load_state_dict(sd)
+    ref.eval()
+    x = micro_doppler_batch(batch, seed=1234)
+    with torch.no_grad():
+        for _ in range(2):
+            ref(x)
+        n, t0 = 0, time.perf_counter()
+        while n < 25 and time.perf_counter() - t0 < seconds:
+            ref(x)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(n * batch / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} forwards of batch {batch}, torch {torch.__version__} fp32 eval fast path, "
+                      f"same weights/inputs generator"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from vit_amd import ops
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+
+    model = CNNViTHybrid(**R_CFG)
+    sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed=0)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    B = args.batch
+    # per-rank synthetic batch (seed differs per rank), generated in chunks, resident in HBM
+    x = torch.cat([micro_doppler_batch(min(64, B - i), seed=1234 + 1000 * rank + i) for i in range(0, B, 64)]).to(dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(x)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(x)
+        sync()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel timing with HIP events on the launch stream (same steps, instrumented) ------
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        rec = []
+        ops.set_profiler(rec)
+        with torch.no_grad():
+            for _ in range(min(args.steps, 5)):
+                model(x)
+        torch.cuda.synchronize(dev)
+        ops.set_profiler(None)
+        for name, e0, e1, fl, nb in rec:
+            k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            k["launches"] += 1
+            k["ms"] += e0.elapsed_time(e1)
+            k["flops"] += fl
+            k["bytes"] += nb
+        dom = max(kernels, key=lambda n: kernels[n]["ms"])
+        k = kernels[dom]
+        avg_ms = k["ms"] / k["launches"]
+        if k["flops"] > 0:
+            ach = k["flops"] / k["launches"] / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": k["launches"] // min(args.steps, 5)}
+        else:
+            ach = k["bytes"] / k["launches"] / (avg_ms * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": k["launches"] // min(args.steps, 5)}
+
+    if rank == 0:
+        frames = world * B * args.steps
+        value = frames / dt
+        out = {
+            "metric": "inference_frames_per_sec", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "cnn_vit_radar hybrid (resnet18 stem + ViT E256/H4/L4, 11 classes) batched "
+                                   "inference, 224x224 synthetic micro-Doppler maps, synthetic weights",
+                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}"},
+            "model_tflops": round(value * FWD_FLOPS_PER_SAMPLE / 1e12, 2),
+            "mfma_util_model": round(value * FWD_FLOPS_PER_SAMPLE / 1e12 / (BF16_MFMA_PEAK_TFLOPS * world), 4),
+            "roofline": roofline,
+            "kernel_ms_per_step": {n: round(v["ms"] / min(args.steps, 5), 4) for n, v in sorted(kernels.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

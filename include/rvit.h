@@ -65,6 +65,14 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
                          int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* scale,
                          const float* bias, const void* residual, int act, int tile, void* stream);
 
+/* Patch-embedding convolution straight into the token stream (pure-ViT `patch16` layout; the
+ * same flatten/transpose/cls-offset/pos_embed epilogue as the 1x1 case, train_vit.py:149-159):
+ * tokens[b, 1+p, :] = conv(x, w)[b, p, :] + bias + pos_embed[1+p, :], fp32 [B, Ho*Wo+1, Cout].
+ * Row 0 of every sample (cls) is left untouched (rvit_embed_cls writes it). */
+int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, int H, int W, int Cpix, int seg_len,
+                           int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* bias,
+                           const float* pos_embed, int tile, void* stream);
+
 /* fp32 NCHW image batch -> zero-haloed bf16 NHWC4 (channel 3 = 0).  Input contract of
  * CNNViTHybrid.forward (train_vit.py:141-146: x is [B,3,224,224] float).  Writes only the
  * interior; the caller zeroes the buffer once. */

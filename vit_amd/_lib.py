@@ -7,6 +7,10 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+import torch  # noqa: F401  -- must be imported BEFORE librvit.so is loaded: torch ships its own
+#                              libamdhip64; loading ours first would bring up a second HIP runtime
+#                              that shares no device context or streams with torch's.
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -30,6 +34,8 @@ SIGNATURES = {
                         c_int, c_int, c_void_p], c_int),
     "rvit_conv2d_fwd_bf16": ([c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_void_p], c_int),
+    "rvit_conv2d_tokens_fwd": ([c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p, c_int, c_void_p],
+                               c_int),
     "rvit_input_pack_nhwc4": ([c_void_p, c_void_p] + [c_int] * 8 + [c_void_p], c_int),
     "rvit_maxpool3x3s2_nhwc": ([c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p], c_int),
     "rvit_embed_cls": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),

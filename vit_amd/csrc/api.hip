@@ -78,6 +78,31 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, int H, int W, int Cpix, int seg_len,
+                           int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* bias,
+                           const float* pos_embed, int tile, void* stream) {
+  RVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+                 "conv_tokens: bad geometry");
+  RVIT_CHECK_ARG((long)B * H * W < 0x7fffffffL, "conv_tokens: B*H*W exceeds 2^31 pixels");
+  RVIT_CHECK_ARG(tokens && pos_embed, "conv_tokens: null pointer");
+  GemmArgs a{};
+  a.A = (const bf16*)x; a.lda = 0;
+  a.B = (const bf16*)w; a.ldb = (long)KH * KW * seg_len;
+  a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * seg_len;
+  a.mode = 1;
+  a.H = H; a.W = W; a.Cpix = Cpix; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.seg_len = seg_len;
+  a.C = tokens; a.ldc = Cout; a.c_f32 = 1;
+  a.bias = bias;
+  a.R = pos_embed + Cout; a.ldr = Cout; a.r_f32 = 1; a.r_period = Ho * Wo;
+  a.row_group = Ho * Wo; a.row_extra = 1;
+  a.act = RVIT_ACT_NONE; a.tile = tile;
+  bool vec = (Cout & 3) == 0 && aligned_to(tokens, 16) && aligned_to(pos_embed, 16);
+  if (bias) vec = vec && aligned_to(bias, 16);
+  a.vec = vec;
+  return rvit_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 int rvit_input_pack_nhwc4(const float* x_nchw, void* out, int B, int C, int H, int W, int Hp, int Wp, int pad_top,
                           int pad_left, void* stream) {
   return rvit_input_pack_impl(x_nchw, out, B, C, H, W, Hp, Wp, pad_top, pad_left, (hipStream_t)stream);

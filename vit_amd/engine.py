@@ -1,0 +1,234 @@
+"""Kernel orchestration for `CNNViTHybrid`: packs parameters into the layouts the HIP kernels read
+and enqueues the forward pass (train_vit.py:141-185) on torch's current stream.
+
+HBM layout (all activations of one forward live in buffers cached per batch size):
+  image      bf16 NHWC4, zero halo          [B, 230, 232, 4]   (patch16: [B,224,224,4], no halo)
+  stem maps  bf16 NHWC                      [B, H, W, C]
+  tokens x   fp32 (the residual stream)     [B, S, E]
+  ln / attn  bf16                           [B*S, E]
+  qkv        bf16  q | k | v                [B*S, 3E]
+  mlp hidden bf16                           [B*S, 4E]
+Weights: bf16 [out, in] (conv: [Cout, kh, kw, Cin]); eval BatchNorm folded to fp32 scale/bias
+applied in the conv epilogue; biases / LN affine / pos_embed stay fp32.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+def _bn_fold(bn):
+    scale = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    bias = bn.bias.float() - bn.running_mean.float() * scale
+    return scale.contiguous(), bias.contiguous()
+
+
+def _pack_conv(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,kh,kw] fp32 -> bf16 [Cout, kh*kw*Cin] (tap-major, channel-contiguous)."""
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(BF16).contiguous()
+
+
+def _pack_conv_px4(w: torch.Tensor, kw_pad: int) -> torch.Tensor:
+    """[Cout,3,kh,kw] -> bf16 [Cout, kh * kw_pad * 4]: per kernel row a run of kw_pad pixels x 4
+    channels (zero taps / zero 4th channel), matching the NHWC4 image rows."""
+    cout, cin, kh, kw = w.shape
+    p = torch.zeros(cout, kh, kw_pad, 4, dtype=torch.float32, device=w.device)
+    p[:, :, :kw, :cin] = w.detach().permute(0, 2, 3, 1)
+    return p.reshape(cout, -1).to(BF16).contiguous()
+
+
+class Engine:
+    """Owns packed weights and per-batch-size activation buffers of one model instance."""
+
+    def __init__(self, model):
+        self.m = model
+        self._pack = None
+        self._pack_key = None
+        self._bufs: Dict[int, Dict[str, torch.Tensor]] = {}
+
+    # ---- weight packing ----------------------------------------------------------------------
+    def _key(self):
+        ps = list(self.m.parameters()) + list(self.m.buffers())
+        return (tuple(p._version for p in ps), ps[0].data_ptr(), ps[0].device, self.m.training)
+
+    @torch.no_grad()
+    def pack(self) -> dict:
+        key = self._key()
+        if self._pack is not None and key == self._pack_key:
+            return self._pack
+        m = self.m
+        dev = m.pos_embed.device
+        if dev.type != "cuda":
+            raise RuntimeError("model parameters must be on a cuda device (no CPU path exists)")
+        P: dict = {"device": dev}
+        if m.cnn_backbone is not None:
+            cb = m.cnn_backbone
+            s, b = _bn_fold(cb.bn1)
+            P["conv1"] = dict(w=_pack_conv_px4(cb.conv1.weight, 8), scale=s, bias=b)
+            blocks = []
+            for blk in cb.blocks():
+                d = {}
+                for nm, conv, bn in (("c1", blk.conv1, blk.bn1), ("c2", blk.conv2, blk.bn2)):
+                    s, b = _bn_fold(bn)
+                    d[nm] = dict(w=_pack_conv(conv.weight), scale=s, bias=b, stride=conv.stride, cout=conv.cout)
+                if blk.downsample is not None:
+                    conv, bn = blk.downsample["0"], blk.downsample["1"]
+                    s, b = _bn_fold(bn)
+                    d["ds"] = dict(w=_pack_conv(conv.weight), scale=s, bias=b, stride=conv.stride, cout=conv.cout)
+                blocks.append(d)
+            P["blocks"] = blocks
+            P["pe_w"] = m.patch_embed.weight.detach().reshape(m.embed_dim, -1).to(BF16).contiguous()
+        else:
+            P["pe_w"] = _pack_conv_px4(m.patch_embed.weight, 16)
+        P["pe_b"] = m.patch_embed.bias.detach().float().contiguous()
+        P["cls"] = m.cls_token.detach().float().reshape(-1).contiguous()
+        P["pos"] = m.pos_embed.detach().float().reshape(-1, m.embed_dim).contiguous()
+        layers = []
+        for L in m.transformer.layers:
+            layers.append(dict(
+                ln1_w=L.norm1.weight.detach().float().contiguous(), ln1_b=L.norm1.bias.detach().float().contiguous(),
+                ln2_w=L.norm2.weight.detach().float().contiguous(), ln2_b=L.norm2.bias.detach().float().contiguous(),
+                qkv_w=L.self_attn.in_proj_weight.detach().to(BF16).contiguous(),
+                qkv_b=L.self_attn.in_proj_bias.detach().float().contiguous(),
+                out_w=L.self_attn.out_proj.weight.detach().to(BF16).contiguous(),
+                out_b=L.self_attn.out_proj.bias.detach().float().contiguous(),
+                fc1_w=L.linear1.weight.detach().to(BF16).contiguous(), fc1_b=L.linear1.bias.detach().float().contiguous(),
+                fc2_w=L.linear2.weight.detach().to(BF16).contiguous(), fc2_b=L.linear2.bias.detach().float().contiguous(),
+                eps1=L.norm1.eps, eps2=L.norm2.eps))
+        P["layers"] = layers
+        P["norm_w"] = m.norm.weight.detach().float().contiguous()
+        P["norm_b"] = m.norm.bias.detach().float().contiguous()
+        P["h0_w"] = m.head["0"].weight.detach().to(BF16).contiguous()
+        P["h0_b"] = m.head["0"].bias.detach().float().contiguous()
+        P["h3_w"] = m.head["3"].weight.detach().to(BF16).contiguous()
+        P["h3_b"] = m.head["3"].bias.detach().float().contiguous()
+        self._pack, self._pack_key = P, key
+        return P
+
+    # ---- activation buffers ------------------------------------------------------------------
+    def buffers(self, B: int, dev) -> Dict[str, torch.Tensor]:
+        bufs = self._bufs.get(B)
+        if bufs is not None and bufs["x"].device == dev:
+            return bufs
+        if len(self._bufs) >= 4:  # keep the cache small: buffers are large
+            self._bufs.pop(next(iter(self._bufs)))
+        m = self.m
+        E, S = m.embed_dim, m.num_patches + 1
+        T = B * S
+        z = dict(dtype=BF16, device=dev)
+        b: Dict[str, torch.Tensor] = {}
+        if m.cnn_backbone is not None:
+            b["img"] = torch.zeros(B, 230, 232, 4, **z)  # halo stays zero forever
+            b["c1"] = torch.empty(B, 112, 112, 64, **z)
+            hw = 56
+            for li, c in enumerate((64, 128, 256, 512), start=1):
+                for nm in ("a", "b", "c", "d"):
+                    b[f"s{li}{nm}"] = torch.empty(B, hw, hw, c, **z)
+                hw //= 2
+        else:
+            b["img"] = torch.zeros(B, 224, 224, 4, **z)
+        b["x"] = torch.empty(B, S, E, dtype=torch.float32, device=dev)
+        b["ln"] = torch.empty(T, E, **z)
+        b["qkv"] = torch.empty(T, 3 * E, **z)
+        b["att"] = torch.empty(T, E, **z)
+        b["hid"] = torch.empty(T, 4 * E, **z)
+        b["cls_ln"] = torch.empty(B, E, **z)
+        b["h0"] = torch.empty(B, E // 2, **z)
+        self._bufs[B] = b
+        return b
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _stem(self, P, b, B) -> torch.Tensor:
+        c1 = P["conv1"]
+        ops.conv2d(b["img"], c1["w"], b["c1"], kh=7, kw=1, stride=2, pad=0, seg_len=32, scale=c1["scale"],
+                   bias=c1["bias"], act="relu")
+        cur = ops.maxpool3x3s2(b["c1"], b["s1a"])
+        stage, free = 1, ["b", "c", "d"]
+        for blk in P["blocks"]:
+            stride = blk["c1"]["stride"]
+            if stride == 2:
+                stage += 1
+                free = ["a", "b", "c", "d"]
+            # pick three scratch maps of this stage that are not `cur`
+            names = [n for n in free if b[f"s{stage}{n}"].data_ptr() != cur.data_ptr()]
+            t, o, dsb = (b[f"s{stage}{n}"] for n in names[:3])
+            idn = cur
+            if "ds" in blk:
+                d = blk["ds"]
+                idn = ops.conv2d(cur, d["w"], dsb, kh=1, kw=1, stride=d["stride"], pad=0, scale=d["scale"],
+                                 bias=d["bias"])
+            a = blk["c1"]
+            ops.conv2d(cur, a["w"], t, kh=3, kw=3, stride=stride, pad=1, scale=a["scale"], bias=a["bias"], act="relu")
+            c = blk["c2"]
+            ops.conv2d(t, c["w"], o, kh=3, kw=3, stride=1, pad=1, scale=c["scale"], bias=c["bias"], residual=idn,
+                       act="relu")
+            cur = o
+            free = ["a", "b", "c", "d"]
+        return cur
+
+    def _encoder_layer(self, L, b, B) -> None:
+        """One pre-LN encoder layer on the fp32 residual stream b["x"], in place
+        (torch transformer.py:945-950: x + sa(norm1(x)); x + ff(norm2(x)))."""
+        m = self.m
+        E, S, H = m.embed_dim, m.num_patches + 1, m.num_heads
+        x2 = b["x"].view(B * S, E)
+        ops.layernorm(x2, L["ln1_w"], L["ln1_b"], b["ln"], L["eps1"])
+        ops.gemm(b["ln"], L["qkv_w"], b["qkv"], bias=L["qkv_b"])
+        ops.attention(b["qkv"], b["att"], B, S, H)
+        ops.gemm(b["att"], L["out_w"], x2, bias=L["out_b"], residual=x2)
+        ops.layernorm(x2, L["ln2_w"], L["ln2_b"], b["ln"], L["eps2"])
+        ops.gemm(b["ln"], L["fc1_w"], b["hid"], bias=L["fc1_b"], act="gelu")
+        ops.gemm(b["hid"], L["fc2_w"], x2, bias=L["fc2_b"], residual=x2)
+
+    @torch.no_grad()
+    def infer(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
+        m = self.m
+        P = self.pack()
+        if x.device != P["device"]:
+            raise RuntimeError(f"input on {x.device} but model on {P['device']}")
+        B = x.shape[0]
+        E, S, H = m.embed_dim, m.num_patches + 1, m.num_heads
+        T = B * S
+        b = self.buffers(B, x.device)
+        xin = x.detach()
+        if xin.dtype != torch.float32:
+            xin = xin.float()
+        xin = xin.contiguous()
+        xs = b["x"]
+        x2 = xs.view(T, E)
+        if m.cnn_backbone is not None:
+            ops.input_pack(xin, b["img"], 3, 3)
+            feat = self._stem(P, b, B)  # [B,7,7,512]
+            ops.gemm(feat.view(B * m.num_patches, -1), P["pe_w"], x2, bias=P["pe_b"], residual=P["pos"][1:],
+                     residual_period=m.num_patches, row_group=m.num_patches, row_extra=1)
+        else:
+            ops.input_pack(xin, b["img"], 0, 0)
+            ops.conv2d_tokens(b["img"], P["pe_w"], xs, P["pos"], kh=16, kw=1, stride=16, pad=0, seg_len=64, ho=14,
+                              wo=14, bias=P["pe_b"])
+        ops.embed_cls(P["cls"], P["pos"], xs)
+        for L in P["layers"]:
+            self._encoder_layer(L, b, B)
+        cls_rows = xs.view(B, S * E)[:, :E]
+        if features_only:
+            out = torch.empty(B, E, dtype=torch.float32, device=x.device)
+            ops.layernorm(cls_rows, P["norm_w"], P["norm_b"], out, m.norm.eps)
+            return out
+        ops.layernorm(cls_rows, P["norm_w"], P["norm_b"], b["cls_ln"], m.norm.eps)
+        ops.gemm(b["cls_ln"], P["h0_w"], b["h0"], bias=P["h0_b"], act="gelu")
+        logits = torch.empty(B, m.num_classes, dtype=torch.float32, device=x.device)
+        ops.gemm(b["h0"], P["h3_w"], logits, bias=P["h3_b"])
+        return logits
+
+    def run(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
+        m = self.m
+        if m.training and torch.is_grad_enabled():
+            raise NotImplementedError("training forward/backward through librvit is not wired up yet")
+        if m.training:
+            raise RuntimeError("call model.eval() for inference: BatchNorm batch statistics and dropout of "
+                               "train mode are only available on the training path")
+        return self.infer(x, features_only)

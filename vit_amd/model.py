@@ -1,0 +1,219 @@
+"""`CNNViTHybrid` — drop-in for the reference classifier (train_vit.py:54-185, infer.py:69-180,
+deploy/infer_edge.py:77-159) whose forward/backward run on librvit HIP kernels.
+
+The module only HOLDS parameters (same names, shapes and dtypes as the reference state_dict, so a
+`cnn_vit_radar.pt` checkpoint loads unchanged); it contains no torch.nn arithmetic.
+`forward` hands the parameters to `vit_amd.engine.Engine`, which enqueues HIP kernels.  Calling the
+model on a CPU tensor raises: there is no fallback path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+
+
+class _Conv(nn.Module):
+    """Parameter holder named like nn.Conv2d (weight [Cout,Cin,k,k], optional bias)."""
+
+    def __init__(self, cin: int, cout: int, k: int, stride: int, pad: int, bias: bool = False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+        if bias:
+            bound = 1.0 / math.sqrt(cin * k * k)
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+
+class _BatchNorm(nn.Module):
+    """Parameter/buffer holder named like nn.BatchNorm2d."""
+
+    def __init__(self, c: int, eps: float = 1e-5, momentum: float = 0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _Linear(nn.Module):
+    def __init__(self, fin: int, fout: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.empty(fout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(fin)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _LayerNorm(nn.Module):
+    def __init__(self, e: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(e))
+        self.bias = nn.Parameter(torch.zeros(e))
+
+
+class _BasicBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, stride: int):
+        super().__init__()
+        self.conv1 = _Conv(cin, cout, 3, stride, 1)
+        self.bn1 = _BatchNorm(cout)
+        self.conv2 = _Conv(cout, cout, 3, 1, 1)
+        self.bn2 = _BatchNorm(cout)
+        if stride != 1 or cin != cout:
+            self.downsample = nn.ModuleDict({"0": _Conv(cin, cout, 1, stride, 0), "1": _BatchNorm(cout)})
+        else:
+            self.downsample = None
+
+
+class _ResNetStem(nn.Module):
+    """ResNet-18/34 trunk parameters under timm `features_only` key names (train_vit.py:87)."""
+    DEPTHS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+
+    def __init__(self, name: str):
+        super().__init__()
+        self.conv1 = _Conv(3, 64, 7, 2, 3)
+        self.bn1 = _BatchNorm(64)
+        cin = 64
+        for li, (c, n) in enumerate(zip((64, 128, 256, 512), self.DEPTHS[name]), start=1):
+            blocks = {}
+            for bi in range(n):
+                blocks[str(bi)] = _BasicBlock(cin, c, 2 if (bi == 0 and li > 1) else 1)
+                cin = c
+            setattr(self, f"layer{li}", nn.ModuleDict(blocks))
+
+    def blocks(self):
+        for li in range(1, 5):
+            for blk in getattr(self, f"layer{li}").values():
+                yield blk
+
+
+class _SelfAttn(nn.Module):
+    """nn.MultiheadAttention parameter names and default init (torch activation.py _reset_parameters)."""
+
+    def __init__(self, e: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * e, e))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * e))
+        self.out_proj = _Linear(e, e)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, e: int):
+        super().__init__()
+        self.self_attn = _SelfAttn(e)
+        self.linear1 = _Linear(e, 4 * e)
+        self.linear2 = _Linear(4 * e, e)
+        self.norm1 = _LayerNorm(e)
+        self.norm2 = _LayerNorm(e)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, e: int, n: int):
+        super().__init__()
+        first = _EncoderLayer(e)
+        layers = [first]
+        for _ in range(n - 1):  # nn.TransformerEncoder deep-copies ONE layer (train_vit.py:103-116)
+            clone = _EncoderLayer(e)
+            clone.load_state_dict(first.state_dict())
+            layers.append(clone)
+        self.layers = nn.ModuleList(layers)
+
+
+class CNNViTHybrid(nn.Module):
+    """Hybrid CNN-ViT radar classifier; constructor signature of train_vit.py:76-77 (the
+    infer.py / infer_edge.py variants omit `pretrained_backbone`, which is accepted and ignored
+    here: there is no network to fetch ImageNet weights from — load a checkpoint instead).
+
+    `backbone='patch16'` is this repository's definition of the pure-ViT `vit_radar.pt` layout
+    (SURVEY.md §8c): 16x16/16 patch conv, 196+1 tokens, no cnn_backbone.* keys.
+    """
+
+    # (model_name, output_channels, feature_map_size) — train_vit.py:68-74
+    BACKBONES = {
+        "mobilenetv3": ("mobilenetv3_small_100", 576, 7),
+        "resnet18": ("resnet18", 512, 7),
+        "resnet34": ("resnet34", 512, 7),
+        "efficientnet_b0": ("efficientnet_b0", 1280, 7),
+        "efficientnet_b2": ("efficientnet_b2", 1408, 7),
+        "patch16": ("patch16", 3, 14),
+    }
+    _HIP_STEMS = ("resnet18", "resnet34", "patch16")
+
+    def __init__(self, num_classes, embed_dim=384, num_heads=6, num_layers=6, dropout=0.1,
+                 pretrained_backbone=False, backbone="resnet34"):
+        super().__init__()
+        self.backbone_name = backbone
+        if backbone not in self.BACKBONES:
+            raise ValueError(f"Unknown backbone: {backbone}. Choose from {list(self.BACKBONES.keys())}")
+        if backbone not in self._HIP_STEMS:
+            raise NotImplementedError(f"backbone {backbone!r}: no HIP stem yet (out of scope, SURVEY.md §8f #4)")
+        if embed_dim % num_heads != 0 or embed_dim // num_heads != 64:
+            raise NotImplementedError("HIP attention kernel supports head_dim 64 only "
+                                      f"(embed_dim={embed_dim}, num_heads={num_heads})")
+        _, cnn_out, feat = self.BACKBONES[backbone]
+        self.num_classes, self.embed_dim, self.num_heads, self.num_layers = num_classes, embed_dim, num_heads, num_layers
+        self.dropout = float(dropout)
+        self.num_patches = feat * feat
+        if backbone == "patch16":
+            self.cnn_backbone = None
+            self.patch_embed = _Conv(3, embed_dim, 16, 16, 0, bias=True)
+        else:
+            self.cnn_backbone = _ResNetStem(backbone)
+            self.patch_embed = _Conv(cnn_out, embed_dim, 1, 1, 0, bias=True)
+        # nn.Conv2d default init for patch_embed (reference keeps torch defaults, train_vit.py:93)
+        nn.init.kaiming_uniform_(self.patch_embed.weight, a=math.sqrt(5))
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, embed_dim))
+        self.transformer = _Encoder(embed_dim, num_layers)
+        self.norm = _LayerNorm(embed_dim)
+        self.head = nn.ModuleDict({"0": _Linear(embed_dim, embed_dim // 2), "3": _Linear(embed_dim // 2, num_classes)})
+        self._init_weights()
+        self._engine = None
+
+    def _init_weights(self):  # train_vit.py:132-139
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+        for m in self.head.values():
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            nn.init.zeros_(m.bias)
+
+    # ---- engine plumbing ---------------------------------------------------------------------
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            object.__setattr__(self, "_engine", Engine(self))
+        return self._engine
+
+    def _check_input(self, x: torch.Tensor) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != 224 or x.shape[3] != 224:
+            raise ValueError(f"expected a [B,3,224,224] tensor, got {getattr(x, 'shape', type(x))}")
+        if not x.is_cuda:
+            raise RuntimeError("vit_amd.CNNViTHybrid runs on the GPU through librvit only; move the model and the "
+                               "input to a cuda device. There is no CPU fallback.")
+        return x
+
+    def forward(self, x):
+        """[B,3,224,224] float (ImageNet-normalised, NCHW) -> fp32 logits [B,num_classes]."""
+        return self.engine.run(self._check_input(x), features_only=False)
+
+    def forward_features(self, x):
+        """-> fp32 cls-token features [B,embed_dim] (train_vit.py:173-185)."""
+        return self.engine.run(self._check_input(x), features_only=True)
+
+    def config(self) -> Dict:
+        """`model_config` entry of the checkpoint dict (train_vit.py:999-1007)."""
+        return {"num_classes": self.num_classes, "backbone": self.backbone_name, "embed_dim": self.embed_dim,
+                "num_heads": self.num_heads, "num_layers": self.num_layers, "dropout": self.dropout, "mode": "single"}

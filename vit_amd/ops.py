@@ -16,6 +16,42 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, RVIT_BF16, RVIT_F32, check  # no
 _ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
 
 
+# ---- optional per-launch profiling (bench.py) ----------------------------------------------------
+# When a list is installed with set_profiler(), every wrapper brackets its launch with HIP events on
+# the launch stream and appends (kernel_name, start_event, end_event, algorithmic_flops,
+# algorithmic_bytes).  Disabled (None) in normal operation.
+_PROF = None
+
+
+def set_profiler(records):
+    global _PROF
+    _PROF = records
+
+
+class _Span:
+    __slots__ = ("name", "flops", "bytes", "e0")
+
+    def __init__(self, name, flops, nbytes):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if _PROF is not None and exc[0] is None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            _PROF.append((self.name, self.e0, e1, self.flops, self.bytes))
+        return False
+
+
+def _nbytes(*ts) -> int:
+    return sum(t.numel() * t.element_size() for t in ts if t is not None)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -77,9 +113,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
         if v is not None and (v.dtype != torch.float32 or v.numel() != N or not v.is_contiguous()):
             raise ValueError(f"gemm: {nm} must be contiguous float32 [N]")
     lib = _lib.load()
-    check(lib.rvit_gemm_bf16(a.data_ptr(), lda, w.data_ptr(), ldb, out.data_ptr(), ldc, _dt(out), M, N, K,
-                             _ptr(scale), _ptr(bias), _ptr(residual), ldr, r_dt, residual_period, _ACT[act],
-                             _ptr(preact), ldp, row_group, row_extra, tile, _stream()), "rvit_gemm_bf16")
+    nb = (M * K + N * K) * 2 + M * N * out.element_size() + (M * N * residual.element_size() if residual is not None
+                                                             and not residual_period else 0)
+    with _Span("gemm_bf16", 2 * M * N * K, nb):
+        check(lib.rvit_gemm_bf16(a.data_ptr(), lda, w.data_ptr(), ldb, out.data_ptr(), ldc, _dt(out), M, N, K,
+                                 _ptr(scale), _ptr(bias), _ptr(residual), ldr, r_dt, residual_period, _ACT[act],
+                                 _ptr(preact), ldp, row_group, row_extra, tile, _stream()), "rvit_gemm_bf16")
     return out
 
 
@@ -105,10 +144,37 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
         if v is not None and (v.dtype != torch.float32 or v.numel() != Cout or not v.is_contiguous()):
             raise ValueError(f"conv2d: {nm} must be contiguous float32 [Cout]")
     lib = _lib.load()
-    check(lib.rvit_conv2d_fwd_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cpix, seg, kh, kw, stride,
-                                   pad, Ho, Wo, Cout, _ptr(scale), _ptr(bias), _ptr(residual), _ACT[act], tile,
-                                   _stream()), "rvit_conv2d_fwd_bf16")
+    # algorithmic work: true taps only (the 7x7 stem conv's zero taps / 4th channel are padding)
+    true_k = kh * kw * seg if seg_len is None else kh * (kw * seg - seg // 8 - (seg - seg // 8) // 4)
+    with _Span("conv2d_bf16", 2 * B * Ho * Wo * Cout * true_k, _nbytes(x, w, out, residual)):
+        check(lib.rvit_conv2d_fwd_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cpix, seg, kh, kw, stride,
+                                       pad, Ho, Wo, Cout, _ptr(scale), _ptr(bias), _ptr(residual), _ACT[act], tile,
+                                       _stream()), "rvit_conv2d_fwd_bf16")
     return out
+
+
+def conv2d_tokens(x: torch.Tensor, w: torch.Tensor, tokens: torch.Tensor, pos_embed: torch.Tensor, *, kh: int,
+                  kw: int, stride: int, pad: int, seg_len: int, ho: int, wo: int,
+                  bias: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+    """Patch conv into the fp32 token stream: tokens[b,1+p] = conv(x,w)[b,p] + bias + pos_embed[1+p]."""
+    _need_cuda(x, w, tokens, pos_embed, bias)
+    B, H, W, Cpix = x.shape
+    Bt, S, E = tokens.shape
+    if Bt != B or S != ho * wo + 1 or tokens.dtype != torch.float32 or not tokens.is_contiguous():
+        raise ValueError("conv2d_tokens: tokens must be contiguous float32 [B, ho*wo+1, E]")
+    if w.shape != (E, kh * kw * seg_len) or w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 \
+            or not w.is_contiguous() or not x.is_contiguous():
+        raise ValueError("conv2d_tokens: bad x / w")
+    if pos_embed.dtype != torch.float32 or pos_embed.numel() != S * E or not pos_embed.is_contiguous():
+        raise ValueError("conv2d_tokens: pos_embed must be contiguous float32 [S,E]")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != E or not bias.is_contiguous()):
+        raise ValueError("conv2d_tokens: bias must be contiguous float32 [E]")
+    true_k = kh * (seg_len // 4) * 3  # px4 runs carry 3 real channels
+    with _Span("conv2d_tokens", 2 * B * ho * wo * E * true_k, _nbytes(x, w, tokens)):
+        check(_lib.load().rvit_conv2d_tokens_fwd(x.data_ptr(), w.data_ptr(), tokens.data_ptr(), B, H, W, Cpix,
+                                                 seg_len, kh, kw, stride, pad, ho, wo, E, _ptr(bias),
+                                                 pos_embed.data_ptr(), tile, _stream()), "rvit_conv2d_tokens_fwd")
+    return tokens
 
 
 def input_pack(x: torch.Tensor, out: torch.Tensor, pad_top: int, pad_left: int) -> torch.Tensor:
@@ -121,8 +187,9 @@ def input_pack(x: torch.Tensor, out: torch.Tensor, pad_top: int, pad_left: int) 
     B, C, H, W = x.shape
     if out.shape[0] != B:
         raise ValueError("input_pack: batch mismatch")
-    check(_lib.load().rvit_input_pack_nhwc4(x.data_ptr(), out.data_ptr(), B, C, H, W, out.shape[1], out.shape[2],
-                                            pad_top, pad_left, _stream()), "rvit_input_pack_nhwc4")
+    with _Span("input_pack", 0, x.numel() * 4 + B * H * W * 8):
+        check(_lib.load().rvit_input_pack_nhwc4(x.data_ptr(), out.data_ptr(), B, C, H, W, out.shape[1], out.shape[2],
+                                                pad_top, pad_left, _stream()), "rvit_input_pack_nhwc4")
     return out
 
 
@@ -136,8 +203,9 @@ def maxpool3x3s2(x: torch.Tensor, out: torch.Tensor, argmax: Optional[torch.Tens
         raise ValueError("maxpool: contiguous NHWC required")
     if argmax is not None and (argmax.dtype != torch.uint8 or argmax.shape != out.shape or not argmax.is_contiguous()):
         raise ValueError("maxpool: argmax must be uint8 with out's shape")
-    check(_lib.load().rvit_maxpool3x3s2_nhwc(x.data_ptr(), out.data_ptr(), _ptr(argmax), B, H, W, C, _stream()),
-          "rvit_maxpool3x3s2_nhwc")
+    with _Span("maxpool", 0, _nbytes(x, out, argmax)):
+        check(_lib.load().rvit_maxpool3x3s2_nhwc(x.data_ptr(), out.data_ptr(), _ptr(argmax), B, H, W, C, _stream()),
+              "rvit_maxpool3x3s2_nhwc")
     return out
 
 
@@ -150,8 +218,9 @@ def embed_cls(cls_token: torch.Tensor, pos_embed: torch.Tensor, x: torch.Tensor)
     if cls_token.dtype != torch.float32 or pos_embed.dtype != torch.float32 or cls_token.numel() != E \
             or pos_embed.numel() < E or not pos_embed.is_contiguous() or not cls_token.is_contiguous():
         raise ValueError("embed_cls: cls/pos must be contiguous float32")
-    check(_lib.load().rvit_embed_cls(cls_token.data_ptr(), pos_embed.data_ptr(), x.data_ptr(), B, S, E, _stream()),
-          "rvit_embed_cls")
+    with _Span("embed_cls", 0, B * E * 4):
+        check(_lib.load().rvit_embed_cls(cls_token.data_ptr(), pos_embed.data_ptr(), x.data_ptr(), B, S, E,
+                                         _stream()), "rvit_embed_cls")
     return x
 
 
@@ -168,9 +237,10 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
     for s in (mean, rstd):
         if s is not None and (s.dtype != torch.float32 or s.numel() != rows or not s.is_contiguous()):
             raise ValueError("layernorm: mean/rstd must be contiguous float32 [rows]")
-    check(_lib.load().rvit_layernorm_fwd(x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(),
-                                         out.data_ptr(), _dt(out), ldy, _ptr(mean), _ptr(rstd), rows, E, eps,
-                                         _stream()), "rvit_layernorm_fwd")
+    with _Span("layernorm_fwd", 0, rows * E * (x.element_size() + out.element_size()) + 8 * E):
+        check(_lib.load().rvit_layernorm_fwd(x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(),
+                                             out.data_ptr(), _dt(out), ldy, _ptr(mean), _ptr(rstd), rows, E, eps,
+                                             _stream()), "rvit_layernorm_fwd")
     return out
 
 
@@ -187,6 +257,7 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, lse:
     if lse is not None and (lse.dtype != torch.float32 or lse.numel() != B * H * S or not lse.is_contiguous()):
         raise ValueError("attention: lse must be contiguous float32 [B,H,S]")
     sc = (1.0 / 8.0) if scale is None else float(scale)
-    check(_lib.load().rvit_attn_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, S, H, ldq, ldo, sc, _stream()),
-          "rvit_attn_fwd")
+    with _Span("attn_fwd", 4 * B * H * S * S * 64, _nbytes(qkv, out, lse)):
+        check(_lib.load().rvit_attn_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, S, H, ldq, ldo, sc, _stream()),
+              "rvit_attn_fwd")
     return out
