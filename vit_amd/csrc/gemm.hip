@@ -11,21 +11,37 @@
 //     NHWC activation: the A operand row for output pixel m and k-chunk (kh,kw,c0..) is a
 //     contiguous channel run of the input pixel, gathered with a bounds predicate (zero pad).
 //
-// Structure (gfx950): 256 threads = 4 waves, BMxBN output tile, BK=64, register-staged
-// global->LDS with two LDS buffers (loads of tile t+1 are in flight while tile t is consumed,
-// LDS write after the MFMAs, one barrier per K tile), XOR-swizzled 128-B LDS rows so that every
-// ds_read_b128 fragment read is bank-conflict free, v_mfma_f32_16x16x32_bf16 with the operands
-// swapped (weights as the MFMA "A" side) so that each lane ends up with 4 consecutive output
-// columns of one row -> 8/16-byte vector epilogue accesses.
+// Structure (gfx950): 256 threads = 4 waves, BMxBN output tile, BK=64.  Operand tiles go
+// global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into a 3-deep ring: tile
+// kt+2 is issued while tile kt is consumed, the wave waits with a COUNTED vmcnt so that one tile
+// stays in flight across the single raw s_barrier per K tile.  LDS rows are 128 B; the 16-byte
+// chunk index is XOR-swizzled with (row>>1)&7 — applied on the per-lane SOURCE address (the DMA
+// destination is lane-linear) and again on the ds_read_b128 fragment reads, which makes every
+// fragment read bank-conflict free.  v_mfma_f32_16x16x32_bf16 with the operands swapped (weights
+// as the MFMA "A" side): each lane ends up with 4 consecutive output columns of one row, so the
+// epilogue (scale, bias, residual, ReLU/GELU, optional pre-activation copy, row remap) uses
+// 8/16-byte accesses.  Out-of-image / out-of-range chunks are sourced from a 16-byte zero page.
+// Workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include "common.h"
 #include "rvit_internal.h"
 
 namespace {
 
 constexpr int BK = 64;  // bf16 elements per K tile = 128 B per LDS row
+constexpr int STAGES = 3;
 
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+__device__ uint4 g_zero_page[4];  // never written; source of padded / out-of-range chunks
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER>
@@ -33,6 +49,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MR = WM / 16, NR = WN / 16;
   constexpr int A_IT = BM / 32, B_IT = BN / 32;
+  constexpr int LOADS = A_IT + B_IT;  // global_load_lds instructions per wave per K tile
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_BYTES = (BM + BN) * 128;
@@ -41,83 +58,98 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+  // ---- XCD-aware tile id: blocks b and b+8 share an XCD; give each XCD a contiguous id range ----
   const int ntn = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x - tile_m * ntn;
+  int tid_lin;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tid_lin / ntn, tile_n = tid_lin - tile_m * ntn;
   const long bm0 = (long)tile_m * BM;
   const int bn0 = tile_n * BN;
 
-  const int lrow = t >> 3;  // 0..31
-  const int lc = t & 7;     // 16-byte chunk within the 128-byte K tile row
+  const int lrow = t >> 3;                      // 0..31: row within a 32-row group
+  const int lc = (t & 7) ^ ((t >> 4) & 7);      // source chunk that lands at LDS chunk slot t&7
+  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_page);
 
-  // ---- per-thread A row descriptors -------------------------------------------------------
-  const bf16* a_ptr[A_IT];
-  bool a_ok[A_IT];
-  int hi0[A_IT], wi0[A_IT];
-  int pix0[A_IT];
+  // ---- per-thread row descriptors ---------------------------------------------------------------
+  const bf16* a_row[A_IT];  // plain: row base pointer; gather: unused
+  int a_pix[A_IT];          // gather: pixel index of tap (0,0); -1 marks an out-of-range row
+  int a_hw[A_IT];           // gather: (hi0 << 16) | (wi0 & 0xffff)
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const long grow = bm0 + lrow + 32 * i;
-    a_ok[i] = grow < p.M;
+    const bool ok = grow < p.M;
     if constexpr (GATHER) {
-      const long g = a_ok[i] ? grow : 0;
+      const long g = ok ? grow : 0;
       const int hw = p.Ho * p.Wo;
       const int b = (int)(g / hw);
       const int rem = (int)(g - (long)b * hw);
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      hi0[i] = ho * p.stride - p.pad;
-      wi0[i] = wo * p.stride - p.pad;
-      pix0[i] = (b * p.H + hi0[i]) * p.W + wi0[i];
-      a_ptr[i] = p.A;
+      const int hi0 = ok ? ho * p.stride - p.pad : -20000;
+      const int wi0 = wo * p.stride - p.pad;
+      a_pix[i] = (b * p.H + hi0) * p.W + wi0;
+      a_hw[i] = (hi0 << 16) | (wi0 & 0xffff);
+      a_row[i] = p.A;
     } else {
-      a_ptr[i] = p.A + (a_ok[i] ? grow : 0) * p.lda;
-      hi0[i] = wi0[i] = pix0[i] = 0;
+      a_row[i] = ok ? p.A + grow * p.lda : nullptr;
+      a_pix[i] = 0;
+      a_hw[i] = 0;
     }
   }
-  const bf16* b_ptr[B_IT];
-  bool b_ok[B_IT];
+  const bf16* b_row[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
     const int n = bn0 + lrow + 32 * i;
-    b_ok[i] = n < p.N;
-    b_ptr[i] = p.B + (long)(b_ok[i] ? n : 0) * p.ldb;
+    b_row[i] = n < p.N ? p.B + (long)n * p.ldb : nullptr;
   }
 
-  uint4 ra[A_IT], rb[B_IT];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  // running K position of the NEXT tile to issue (per thread: its own chunk)
+  int k_issue = lc * 8;
+  int g_kh = 0, g_kw = 0, g_off = 0;
+  if constexpr (GATHER) {
+    const int seg = k_issue / p.seg_len;
+    g_off = k_issue - seg * p.seg_len;
+    g_kh = seg / p.KW;
+    g_kw = seg - g_kh * p.KW;
+  }
 
-  auto stage_load = [&](int kt) {
-    const int k = kt * BK + lc * 8;
-    const bool k_ok = k < p.K;
-    if constexpr (GATHER) {
-      const int seg = k / p.seg_len;
-      const int off = k - seg * p.seg_len;
-      const int kh = seg / p.KW;
-      const int kw = seg - kh * p.KW;
-      const int dpix = kh * p.W + kw;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const int hi = hi0[i] + kh, wi = wi0[i] + kw;
-        const bool ok = a_ok[i] && k_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        const bf16* src = p.A + (long)(pix0[i] + dpix) * p.Cpix + off;
-        ra[i] = ok ? *reinterpret_cast<const uint4*>(src) : zero4;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i)
-        ra[i] = (a_ok[i] && k_ok) ? *reinterpret_cast<const uint4*>(a_ptr[i] + k) : zero4;
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-      rb[i] = (b_ok[i] && k_ok) ? *reinterpret_cast<const uint4*>(b_ptr[i] + k) : zero4;
-  };
-  auto stage_write = [&](int buf) {
-    char* sA = smem + buf * TILE_BYTES;
-    char* sB = sA + BM * 128;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(sA + lds_off(lrow + 32 * i, lc)) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(sB + lds_off(lrow + 32 * i, lc)) = rb[i];
-  };
+  char* const wave_dst = smem + wave * 1024;  // + stage*TILE_BYTES + i*4096 (+ BM*128 for B)
+
+#define ISSUE_TILE(stage)                                                                        \
+  do {                                                                                           \
+    char* dstA = wave_dst + (stage) * TILE_BYTES;                                                \
+    char* dstB = dstA + BM * 128;                                                                \
+    const bool k_ok = k_issue < p.K;                                                             \
+    if constexpr (GATHER) {                                                                      \
+      const int dpix = g_kh * p.W + g_kw;                                                        \
+      _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                         \
+        const int hi = (a_hw[i] >> 16) + g_kh, wi = (int)(short)(a_hw[i] & 0xffff) + g_kw;       \
+        const bool ok = k_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;    \
+        const bf16* src = ok ? p.A + (long)(a_pix[i] + dpix) * p.Cpix + g_off : zero_src;        \
+        glds16(src, dstA + i * 4096);                                                            \
+      }                                                                                          \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                         \
+        const bf16* src = (k_ok && a_row[i]) ? a_row[i] + k_issue : zero_src;                    \
+        glds16(src, dstA + i * 4096);                                                            \
+      }                                                                                          \
+    }                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                           \
+      const bf16* src = (k_ok && b_row[i]) ? b_row[i] + k_issue : zero_src;                      \
+      glds16(src, dstB + i * 4096);                                                              \
+    }                                                                                            \
+    k_issue += BK;                                                                               \
+    if constexpr (GATHER) {                                                                      \
+      g_off += BK;                                                                               \
+      while (g_off >= p.seg_len) {                                                               \
+        g_off -= p.seg_len;                                                                      \
+        if (++g_kw == p.KW) { g_kw = 0; ++g_kh; }                                                \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
 
   f32x4 acc[MR][NR];
 #pragma unroll
@@ -126,34 +158,44 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  stage_load(0);
-  stage_write(0);
-  __syncthreads();
+  // prologue: two tiles in flight (a tile past K is all zero pages: harmless, keeps counts fixed)
+  ISSUE_TILE(0);
+  ISSUE_TILE(1);
 
   const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;  // (row>>1)&7 for every fragment row of this lane
+  int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) stage_load(kt + 1);
-    const char* sA = smem + buf * TILE_BYTES;
+    // tile kt landed (this wave's share): leave only tile kt+1's loads in flight
+    wait_vmcnt<LOADS>();
+    __builtin_amdgcn_s_barrier();  // every wave's share landed; every wave finished tile kt-1
+    {
+      int st2 = stage + 2;
+      if (st2 >= STAGES) st2 -= STAGES;
+      ISSUE_TILE(st2);  // overwrites the buffer of tile kt-1
+    }
+    const char* sA = smem + stage * TILE_BYTES;
     const char* sB = sA + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[MR], bfr[NR];
+      const int coff = ((ks * 4 + fq) ^ sw) << 4;
 #pragma unroll
       for (int i = 0; i < MR; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WM + i * 16 + fr, ks * 4 + fq));
+        af[i] = *reinterpret_cast<const bf16x8*>(sA + (wm * WM + i * 16 + fr) * 128 + coff);
 #pragma unroll
       for (int j = 0; j < NR; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WN + j * 16 + fr, ks * 4 + fq));
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sB + (wn * WN + j * 16 + fr) * 128 + coff);
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) stage_write(buf ^ 1);
-    __syncthreads();
+    if (++stage == STAGES) stage = 0;
   }
+  wait_vmcnt<0>();  // drain the zero-page tiles issued past K before the LDS is released
+#undef ISSUE_TILE
 
   // ---- epilogue: lane holds rows n = nbase + 4*fq + {0..3} of column m = mbase + fr ----------
 #pragma unroll
@@ -238,7 +280,19 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     rvit_set_error("gemm: too many tiles (%ld)", tiles);
     return RVIT_EINVAL;
   }
-  const size_t lds = 2 * (BM + BN) * 128;
+  constexpr int lds = STAGES * (BM + BN) * 128;
+  static bool attr_done = false;
+  if (lds > 65536 && !attr_done) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      rvit_set_error("gemm: cannot raise the dynamic LDS limit to %d bytes", lds);
+      return RVIT_ELAUNCH;
+    }
+    attr_done = true;
+  }
   if (a.mode == 1)
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3((unsigned)tiles), dim3(256), lds, stream, a);
   else
@@ -260,7 +314,7 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   } else {
     RVIT_CHECK_ARG((a.Cpix & 3) == 0 && (a.seg_len & 7) == 0 && a.seg_len > 0 && a.KW > 0,
                    "conv: bad gather geometry Cpix=%d seg_len=%d KW=%d", a.Cpix, a.seg_len, a.KW);
-    RVIT_CHECK_ARG(((long)a.Cpix * 2) % 8 == 0, "conv: pixel pitch must keep 16-byte chunk alignment");
+    RVIT_CHECK_ARG(a.H < 20000 && a.W < 20000, "conv: image too large for packed coordinates");
   }
   if (a.M == 0) return RVIT_OK;
   const int forced = a.tile;
