@@ -28,7 +28,6 @@
 namespace {
 
 constexpr int BK = 64;  // bf16 elements per K tile = 128 B per LDS row
-constexpr int STAGES = 3;
 
 __device__ uint4 g_zero_page[4];  // never written; source of padded / out-of-range chunks
 
@@ -44,13 +43,15 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool GATHER>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool GATHER>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const GemmArgs p) {
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int MR = WM / 16, NR = WN / 16;
-  constexpr int A_IT = BM / 32, B_IT = BN / 32;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int RPP = NT / 8;  // tile rows covered by one global_load_lds pass of the workgroup
+  constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
   constexpr int LOADS = A_IT + B_IT;  // global_load_lds instructions per wave per K tile
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && STAGES >= 2, "tile / thread-count mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TILE_BYTES = (BM + BN) * 128;
 
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
   const long bm0 = (long)tile_m * BM;
   const int bn0 = tile_n * BN;
 
-  const int lrow = t >> 3;                      // 0..31: row within a 32-row group
+  const int lrow = t >> 3;                      // row within an RPP-row pass
   const int lc = (t & 7) ^ ((t >> 4) & 7);      // source chunk that lands at LDS chunk slot t&7
   const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_page);
 
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
   int a_hw[A_IT];           // gather: (hi0 << 16) | (wi0 & 0xffff)
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const long grow = bm0 + lrow + 32 * i;
+    const long grow = bm0 + lrow + RPP * i;
     const bool ok = grow < p.M;
     if constexpr (GATHER) {
       const long g = ok ? grow : 0;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
   const bf16* b_row[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int n = bn0 + lrow + 32 * i;
+    const int n = bn0 + lrow + RPP * i;
     b_row[i] = n < p.N ? p.B + (long)n * p.ldb : nullptr;
   }
 
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     g_kw = seg - g_kh * p.KW;
   }
 
-  char* const wave_dst = smem + wave * 1024;  // + stage*TILE_BYTES + i*4096 (+ BM*128 for B)
+  char* const wave_dst = smem + wave * 1024;  // + stage*TILE_BYTES + i*RPP*128 (+ BM*128 for B)
 
 #define ISSUE_TILE(stage)                                                                        \
   do {                                                                                           \
@@ -129,17 +130,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
         const int hi = (a_hw[i] >> 16) + g_kh, wi = (int)(short)(a_hw[i] & 0xffff) + g_kw;       \
         const bool ok = k_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;    \
         const bf16* src = ok ? p.A + (long)(a_pix[i] + dpix) * p.Cpix + g_off : zero_src;        \
-        glds16(src, dstA + i * 4096);                                                            \
+        glds16(src, dstA + i * (RPP * 128));                                                            \
       }                                                                                          \
     } else {                                                                                     \
       _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                         \
         const bf16* src = (k_ok && a_row[i]) ? a_row[i] + k_issue : zero_src;                    \
-        glds16(src, dstA + i * 4096);                                                            \
+        glds16(src, dstA + i * (RPP * 128));                                                            \
       }                                                                                          \
     }                                                                                            \
     _Pragma("unroll") for (int i = 0; i < B_IT; ++i) {                                           \
       const bf16* src = (k_ok && b_row[i]) ? b_row[i] + k_issue : zero_src;                      \
-      glds16(src, dstB + i * 4096);                                                              \
+      glds16(src, dstB + i * (RPP * 128));                                                              \
     }                                                                                            \
     k_issue += BK;                                                                               \
     if constexpr (GATHER) {                                                                      \
@@ -158,19 +159,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
     for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  // prologue: two tiles in flight (a tile past K is all zero pages: harmless, keeps counts fixed)
-  ISSUE_TILE(0);
-  ISSUE_TILE(1);
+  // prologue: STAGES-1 tiles in flight (a tile past K is all zero pages: harmless, keeps the
+  // counted waits fixed)
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s) ISSUE_TILE(s);
 
   const int fr = lane & 15, fq = lane >> 4;
   const int sw = (fr >> 1) & 7;  // (row>>1)&7 for every fragment row of this lane
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt landed (this wave's share): leave only tile kt+1's loads in flight
-    wait_vmcnt<LOADS>();
+    // tile kt landed (this wave's share): leave only the younger tiles' loads in flight
+    wait_vmcnt<LOADS*(STAGES - 2)>();
     __builtin_amdgcn_s_barrier();  // every wave's share landed; every wave finished tile kt-1
     {
-      int st2 = stage + 2;
+      int st2 = stage + STAGES - 1;
       if (st2 >= STAGES) st2 -= STAGES;
       ISSUE_TILE(st2);  // overwrites the buffer of tile kt-1
     }
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   const long tiles = ((a.M + BM - 1) / BM) * (long)((a.N + BN - 1) / BN);
   if (tiles <= 0) return RVIT_OK;
@@ -283,9 +285,9 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = STAGES * (BM + BN) * 128;
   static bool attr_done = false;
   if (lds > 65536 && !attr_done) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, true>,
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, false>,
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e1 != hipSuccess || e2 != hipSuccess) {
       rvit_set_error("gemm: cannot raise the dynamic LDS limit to %d bytes", lds);
@@ -294,9 +296,9 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     attr_done = true;
   }
   if (a.mode == 1)
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, true>), dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, true>), dim3((unsigned)tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
   else
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, false>), dim3((unsigned)tiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, false>), dim3((unsigned)tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
   RVIT_CHECK_LAUNCH("gemm_bf16");
   return RVIT_OK;
 }
@@ -318,16 +320,25 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   }
   if (a.M == 0) return RVIT_OK;
   const int forced = a.tile;
-  const long t128 = ((a.M + 127) / 128) * (long)((a.N + 127) / 128);
+  // Measured on MI355X (profiles/r01_tile_sweep.txt): the 256x64 tile with 8 waves and two LDS
+  // stages (80 KB -> 2 workgroups = 16 waves per CU) wins on every stem / encoder shape; smaller
+  // tiles only when the problem cannot fill the chip.
+  const long n64 = (a.N + 63) / 64;
   int cfg;
   if (forced) cfg = forced;
-  else if (a.N > 64 && t128 >= 384) cfg = 1;
-  else if (((a.M + 127) / 128) * (long)((a.N + 63) / 64) >= 256) cfg = 2;
+  else if (((a.M + 255) / 256) * n64 >= 384) cfg = 7;
+  else if (((a.M + 127) / 128) * n64 >= 256) cfg = 2;
   else cfg = 3;
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2>(a, stream);
-    case 2: return launch_cfg<128, 64, 2, 2>(a, stream);
-    case 3: return launch_cfg<64, 64, 2, 2>(a, stream);
+    case 1: return launch_cfg<128, 128, 2, 2, 2>(a, stream);
+    case 2: return launch_cfg<128, 64, 2, 2, 2>(a, stream);
+    case 3: return launch_cfg<64, 64, 2, 2, 2>(a, stream);
+    case 4: return launch_cfg<256, 128, 4, 2, 2>(a, stream);
+    case 5: return launch_cfg<128, 128, 2, 4, 3>(a, stream);
+    case 6: return launch_cfg<128, 128, 2, 2, 3>(a, stream);
+    case 7: return launch_cfg<256, 64, 4, 2, 2>(a, stream);
+    case 8: return launch_cfg<128, 64, 2, 2, 3>(a, stream);
+    case 9: return launch_cfg<256, 128, 4, 2, 3>(a, stream);
     default: rvit_set_error("gemm: unknown tile config %d", cfg); return RVIT_EINVAL;
   }
 }
