@@ -48,7 +48,7 @@ const char* rvit_last_error(void);
  *   C: bf16 or f32 [.,ldc];  preact (optional, bf16 [.,ldp]) receives the value before R/act
  *   R: optional residual (bf16 or f32), row = m % r_period when r_period > 0, else the C row
  *   row_group > 0 remaps the output row: (m / g) * (g + row_extra) + m % g + row_extra
- *   tile: 0 = automatic tile choice, 1/2/3 force 128x128 / 128x64 / 64x64 (testing). */
+ *   tile: 0 = automatic tile choice, 1/2/3 force 256x64 / 128x64 / 64x64 (testing). */
 int rvit_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype,
                    int64_t M, int N, int K, const float* scale, const float* bias, const void* R, int64_t ldr,
                    int r_dtype, int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra,

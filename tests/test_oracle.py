@@ -1,0 +1,91 @@
+"""CPU-only checks that pin what can be pinned about the oracle (oracle/ref_model.py):
+  * its tail is the reference's own torch.nn modules/arguments (train_vit.py:93-127): state_dict
+    keys and shapes equal the list the reference source implies;
+  * torch's eval fast path and the train-mode slow path of the encoder agree;
+  * vit_amd.CNNViTHybrid exposes exactly the same keys/shapes (drop-in checkpoint layout);
+  * the bf16 emulation stays within the documented distance of the fp32 oracle.
+The stem (timm resnet18) is PARITY UNPINNED: no reference-held vector covers it (see the oracle
+header)."""
+import torch
+
+from oracle.ref_model import CNNViTHybridRef
+
+R = dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18")
+
+
+def _expected_tail(E, L, S, C, ncls):
+    exp = {"cls_token": (1, 1, E), "pos_embed": (1, S, E), "patch_embed.weight": (E, C, 1, 1), "patch_embed.bias": (E,)}
+    for i in range(L):
+        p = f"transformer.layers.{i}."
+        exp.update({p + "self_attn.in_proj_weight": (3 * E, E), p + "self_attn.in_proj_bias": (3 * E,),
+                    p + "self_attn.out_proj.weight": (E, E), p + "self_attn.out_proj.bias": (E,),
+                    p + "linear1.weight": (4 * E, E), p + "linear1.bias": (4 * E,),
+                    p + "linear2.weight": (E, 4 * E), p + "linear2.bias": (E,),
+                    p + "norm1.weight": (E,), p + "norm1.bias": (E,), p + "norm2.weight": (E,), p + "norm2.bias": (E,)})
+    exp.update({"norm.weight": (E,), "norm.bias": (E,), "head.0.weight": (E // 2, E), "head.0.bias": (E // 2,),
+                "head.3.weight": (ncls, E // 2), "head.3.bias": (ncls,)})
+    return exp
+
+
+def test_tail_state_dict_layout_matches_reference_source():
+    ref = CNNViTHybridRef(**R)
+    sd = {k: tuple(v.shape) for k, v in ref.state_dict().items() if not k.startswith("cnn_backbone.")}
+    assert sd == _expected_tail(256, 4, 50, 512, 11)
+    assert len(sd) == 22 + 12 * 3  # 22 + 12*(L-1) tensors
+
+
+def test_stem_key_names_follow_timm_feature_list_net():
+    ref = CNNViTHybridRef(**R)
+    keys = [k for k in ref.state_dict() if k.startswith("cnn_backbone.")]
+    assert "cnn_backbone.conv1.weight" in keys and "cnn_backbone.bn1.running_var" in keys
+    assert "cnn_backbone.layer2.0.downsample.0.weight" in keys and "cnn_backbone.layer4.1.bn2.num_batches_tracked" in keys
+    assert not any(".fc." in k for k in keys)
+    n_params = sum(v.numel() for k, v in ref.state_dict().items()
+                   if k.startswith("cnn_backbone.") and "running" not in k and "num_batches" not in k)
+    assert n_params == 11_176_512  # resnet18 minus fc
+
+
+def test_product_module_has_the_same_checkpoint_layout():
+    from vit_amd.model import CNNViTHybrid
+    for cfg in (R, dict(R, backbone="resnet34"), dict(R, backbone="patch16", embed_dim=768, num_heads=12, num_layers=2)):
+        ref, m = CNNViTHybridRef(**cfg), CNNViTHybrid(**cfg)
+        a = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+        b = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert a == b and list(a) == list(b)
+    assert sum(p.numel() for p in CNNViTHybrid(**R).parameters()) == 14_514_763
+
+
+def test_encoder_fast_and_slow_paths_agree():
+    from vit_amd.synth import synth_state_dict
+    cfg = dict(R, backbone="patch16")
+    ref = CNNViTHybridRef(**cfg)
+    ref.load_state_dict(synth_state_dict({k: v.shape for k, v in ref.state_dict().items()}, 3))
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    ref.eval()
+    with torch.no_grad():
+        fast = ref(x)
+    slow = ref(x)  # grad enabled -> torch takes the per-op slow path
+    assert (fast - slow.detach()).abs().max() < 5e-5
+
+
+def test_unknown_backbone_raises_value_error():
+    import pytest
+    from vit_amd.model import CNNViTHybrid
+    with pytest.raises(ValueError):
+        CNNViTHybrid(11, backbone="vgg")
+    with pytest.raises(ValueError):
+        CNNViTHybridRef(11, backbone="vgg")
+
+
+def test_bf16_emulation_distance_to_fp32_oracle():
+    from oracle.ref_bf16 import forward_bf16_emulated
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    ref = CNNViTHybridRef(**R).eval()
+    sd = synth_state_dict({k: v.shape for k, v in ref.state_dict().items()}, 1)
+    ref.load_state_dict(sd)
+    x = micro_doppler_batch(4, seed=77)
+    with torch.no_grad():
+        want = ref(x)
+    emu = forward_bf16_emulated(sd, x, R)
+    assert (emu - want).abs().max() < 0.35
+    assert (emu.argmax(1) == want.argmax(1)).all()

@@ -41,11 +41,12 @@ int rvit_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   RVIT_CHECK_ARG(act >= 0 && act <= 2, "gemm: bad act %d", act);
   RVIT_CHECK_ARG(ldc >= N && (!R || ldr >= N) && (!preact || ldp >= N), "gemm: output pitch smaller than N");
   RVIT_CHECK_ARG(row_group >= 0 && row_extra >= 0 && r_period >= 0, "gemm: negative row remap");
-  bool vec = (N & 3) == 0 && (ldc & 3) == 0 && aligned_to(C, a.c_f32 ? 16 : 8);
+  // vector epilogue: 8 consecutive columns per lane, 16-byte accesses
+  bool vec = (N & 7) == 0 && (ldc & (a.c_f32 ? 3 : 7)) == 0 && aligned_to(C, 16);
   if (scale) vec = vec && aligned_to(scale, 16);
   if (bias) vec = vec && aligned_to(bias, 16);
-  if (R) vec = vec && (ldr & 3) == 0 && aligned_to(R, a.r_f32 ? 16 : 8);
-  if (preact) vec = vec && (ldp & 3) == 0 && aligned_to(preact, 8);
+  if (R) vec = vec && (ldr & (a.r_f32 ? 3 : 7)) == 0 && aligned_to(R, 16);
+  if (preact) vec = vec && (ldp & 7) == 0 && aligned_to(preact, 16);
   a.vec = vec;
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
@@ -70,10 +71,10 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
   a.R = residual; a.ldr = Cout; a.r_f32 = 0; a.r_period = 0;
   a.act = act; a.tile = tile;
   RVIT_CHECK_ARG(act >= 0 && act <= 2, "conv: bad act %d", act);
-  bool vec = (Cout & 3) == 0 && aligned_to(y, 8);
+  bool vec = (Cout & 7) == 0 && aligned_to(y, 16);
   if (scale) vec = vec && aligned_to(scale, 16);
   if (bias) vec = vec && aligned_to(bias, 16);
-  if (residual) vec = vec && aligned_to(residual, 8);
+  if (residual) vec = vec && aligned_to(residual, 16);
   a.vec = vec;
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
@@ -97,7 +98,7 @@ int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, i
   a.R = pos_embed + Cout; a.ldr = Cout; a.r_f32 = 1; a.r_period = Ho * Wo;
   a.row_group = Ho * Wo; a.row_extra = 1;
   a.act = RVIT_ACT_NONE; a.tile = tile;
-  bool vec = (Cout & 3) == 0 && aligned_to(tokens, 16) && aligned_to(pos_embed, 16);
+  bool vec = (Cout & 7) == 0 && aligned_to(tokens, 16) && aligned_to(pos_embed, 16);
   if (bias) vec = vec && aligned_to(bias, 16);
   a.vec = vec;
   return rvit_gemm_dispatch(a, (hipStream_t)stream);

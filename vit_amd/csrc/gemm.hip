@@ -11,16 +11,16 @@
 //     NHWC activation: the A operand row for output pixel m and k-chunk (kh,kw,c0..) is a
 //     contiguous channel run of the input pixel, gathered with a bounds predicate (zero pad).
 //
-// Structure (gfx950): 256 threads = 4 waves, BMxBN output tile, BK=64.  Operand tiles go
+// Structure (gfx950): 2/4/8 waves, each owning a 32x64 slice of a {64,128,256}x64 output tile, BK=64.  Operand tiles go
 // global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into a 3-deep ring: tile
 // kt+2 is issued while tile kt is consumed, the wave waits with a COUNTED vmcnt so that one tile
 // stays in flight across the single raw s_barrier per K tile.  LDS rows are 128 B; the 16-byte
 // chunk index is XOR-swizzled with (row>>1)&7 — applied on the per-lane SOURCE address (the DMA
 // destination is lane-linear) and again on the ds_read_b128 fragment reads, which makes every
 // fragment read bank-conflict free.  v_mfma_f32_16x16x32_bf16 with the operands swapped (weights
-// as the MFMA "A" side): each lane ends up with 4 consecutive output columns of one row, so the
-// epilogue (scale, bias, residual, ReLU/GELU, optional pre-activation copy, row remap) uses
-// 8/16-byte accesses.  Out-of-image / out-of-range chunks are sourced from a 16-byte zero page.
+// as the MFMA "A" side): each lane ends up with 4 consecutive output columns of one row; the
+// epilogue (scale, bias, residual, ReLU/GELU, optional pre-activation copy, row remap) restages
+// the tile through LDS so that all its global accesses are whole 128-byte row segments.  Out-of-image / out-of-range chunks are sourced from a 16-byte zero page.
 // Workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include "common.h"
 #include "rvit_internal.h"
@@ -199,76 +199,101 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
   wait_vmcnt<0>();  // drain the zero-page tiles issued past K before the LDS is released
 #undef ISSUE_TILE
 
-  // ---- epilogue: lane holds rows n = nbase + 4*fq + {0..3} of column m = mbase + fr ----------
+  // ---- epilogue -----------------------------------------------------------------------------
+  // The accumulators (lane: 4 consecutive columns of one row) are staged as fp32 through a
+  // wave-private LDS region and read back row-major, 8 consecutive columns per lane, so every
+  // global access of the epilogue (C, preact copy, residual) is a full 128-B row segment per
+  // 8 lanes instead of 8-byte pieces strided over 16 rows.
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the operand ring
+  constexpr int EP_PITCH = WN * 4 + 16;
+  static_assert(WAVES_N == 1 && WN == 64, "epilogue assumes one wave spans the 64-column tile");
+  static_assert(WAVES_M * WM * EP_PITCH <= STAGES * TILE_BYTES, "epilogue staging exceeds the ring");
+  char* ep = smem + wave * (WM * EP_PITCH);
 #pragma unroll
-  for (int i = 0; i < MR; ++i) {
-    const long m = bm0 + wm * WM + i * 16 + fr;
-    if (m >= p.M) continue;
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+      *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i][j];
+  __syncthreads();
+  const int er = lane >> 3, ec = (lane & 7) * 8;
+  const int n = bn0 + ec;
+#pragma unroll
+  for (int pass = 0; pass < WM / 8; ++pass) {
+    const int row = pass * 8 + er;
+    const long m = bm0 + wm * WM + row;
+    if (m >= p.M || n >= p.N) continue;
     long orow = m;
     if (p.row_group > 0) {
       const long g = m / p.row_group;
       orow = g * (p.row_group + p.row_extra) + (m - g * p.row_group) + p.row_extra;
     }
     const long rrow = p.r_period > 0 ? (m % p.r_period) : orow;
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int n = bn0 + wn * WN + j * 16 + fq * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[i][j];
-      if (p.vec) {
-        if (p.scale) {
-          const float4 s = *reinterpret_cast<const float4*>(p.scale + n);
-          v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
-        }
-        if (p.bias) {
-          const float4 s = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
-        }
-        if (p.C2) {
-          uint2 o;
-          o.x = pack_bf16x2(v[0], v[1]);
-          o.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<uint2*>(p.C2 + orow * p.ldc2 + n) = o;
-        }
-        if (p.R) {
-          if (p.r_f32) {
-            const float4 r = *reinterpret_cast<const float4*>((const float*)p.R + rrow * p.ldr + n);
-            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-          } else {
-            const uint2 r = *reinterpret_cast<const uint2*>((const bf16*)p.R + rrow * p.ldr + n);
-            v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
-          }
-        }
-        if (p.act == RVIT_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == RVIT_ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        }
-        if (p.c_f32) {
-          *reinterpret_cast<float4*>((float*)p.C + orow * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+    float v[8];
+    {
+      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4);
+      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4 + 16);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
+    if (p.vec) {
+      if (p.scale) {
+        const float4 a = *reinterpret_cast<const float4*>(p.scale + n);
+        const float4 b = *reinterpret_cast<const float4*>(p.scale + n + 4);
+        v[0] *= a.x; v[1] *= a.y; v[2] *= a.z; v[3] *= a.w; v[4] *= b.x; v[5] *= b.y; v[6] *= b.z; v[7] *= b.w;
+      }
+      if (p.bias) {
+        const float4 a = *reinterpret_cast<const float4*>(p.bias + n);
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      }
+      if (p.C2) {
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(p.C2 + orow * p.ldc2 + n) = o;
+      }
+      if (p.R) {
+        if (p.r_f32) {
+          const float* rp = (const float*)p.R + rrow * p.ldr + n;
+          const float4 a = *reinterpret_cast<const float4*>(rp);
+          const float4 b = *reinterpret_cast<const float4*>(rp + 4);
+          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
         } else {
-          uint2 o;
-          o.x = pack_bf16x2(v[0], v[1]);
-          o.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<uint2*>((bf16*)p.C + orow * p.ldc + n) = o;
+          const uint4 r = *reinterpret_cast<const uint4*>((const bf16*)p.R + rrow * p.ldr + n);
+          v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+          v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
         }
-      } else {
+      }
+      if (p.act == RVIT_ACT_RELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (n + e >= p.N) break;
-          float x = v[e];
-          if (p.scale) x *= p.scale[n + e];
-          if (p.bias) x += p.bias[n + e];
-          if (p.C2) p.C2[orow * p.ldc2 + n + e] = (bf16)x;
-          if (p.R) x += p.r_f32 ? ((const float*)p.R)[rrow * p.ldr + n + e]
-                                : (float)((const bf16*)p.R)[rrow * p.ldr + n + e];
-          if (p.act == RVIT_ACT_RELU) x = fmaxf(x, 0.f);
-          else if (p.act == RVIT_ACT_GELU) x = gelu_erf(x);
-          if (p.c_f32) ((float*)p.C)[orow * p.ldc + n + e] = x;
-          else ((bf16*)p.C)[orow * p.ldc + n + e] = (bf16)x;
-        }
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (p.act == RVIT_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if (p.c_f32) {
+        float* cp = (float*)p.C + orow * p.ldc + n;
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4*>((bf16*)p.C + orow * p.ldc + n) = o;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (n + e >= p.N) break;
+        float x = v[e];
+        if (p.scale) x *= p.scale[n + e];
+        if (p.bias) x += p.bias[n + e];
+        if (p.C2) p.C2[orow * p.ldc2 + n + e] = (bf16)x;
+        if (p.R) x += p.r_f32 ? ((const float*)p.R)[rrow * p.ldr + n + e]
+                              : (float)((const bf16*)p.R)[rrow * p.ldr + n + e];
+        if (p.act == RVIT_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (p.act == RVIT_ACT_GELU) x = gelu_erf(x);
+        if (p.c_f32) ((float*)p.C)[orow * p.ldc + n + e] = x;
+        else ((bf16*)p.C)[orow * p.ldc + n + e] = (bf16)x;
       }
     }
   }
@@ -326,19 +351,13 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   const long n64 = (a.N + 63) / 64;
   int cfg;
   if (forced) cfg = forced;
-  else if (((a.M + 255) / 256) * n64 >= 384) cfg = 7;
+  else if (((a.M + 255) / 256) * n64 >= 384) cfg = 1;
   else if (((a.M + 127) / 128) * n64 >= 256) cfg = 2;
   else cfg = 3;
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2, 2>(a, stream);
-    case 2: return launch_cfg<128, 64, 2, 2, 2>(a, stream);
-    case 3: return launch_cfg<64, 64, 2, 2, 2>(a, stream);
-    case 4: return launch_cfg<256, 128, 4, 2, 2>(a, stream);
-    case 5: return launch_cfg<128, 128, 2, 4, 3>(a, stream);
-    case 6: return launch_cfg<128, 128, 2, 2, 3>(a, stream);
-    case 7: return launch_cfg<256, 64, 4, 2, 2>(a, stream);
-    case 8: return launch_cfg<128, 64, 2, 2, 3>(a, stream);
-    case 9: return launch_cfg<256, 128, 4, 2, 3>(a, stream);
+    case 1: return launch_cfg<256, 64, 8, 1, 2>(a, stream);
+    case 2: return launch_cfg<128, 64, 4, 1, 2>(a, stream);
+    case 3: return launch_cfg<64, 64, 2, 1, 2>(a, stream);
     default: rvit_set_error("gemm: unknown tile config %d", cfg); return RVIT_EINVAL;
   }
 }

@@ -29,7 +29,7 @@ struct GemmArgs {
   int act;
   int row_group;     // >0: output row = (m / g) * (g + row_extra) + m % g + row_extra
   int row_extra;
-  int vec;           // 1: N, ld* and pointers allow 4-wide vector epilogue accesses
+  int vec;           // 1: N, ld* and pointers allow 8-wide (16-byte) vector epilogue accesses
   int tile;          // 0 = auto, else forced tile config (tests)
 };
 
