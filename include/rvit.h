@@ -2,9 +2,10 @@
  *
  * The reference (bheering007/ViT) has no FFI/plugin interface: its hot path is the nn.Module
  * `CNNViTHybrid` (train_vit.py:54-185) calling torch.nn arithmetic.  Every entry below replaces
- * one of those torch calls; the cited file:line is the reference (or torch) call site whose
- * arithmetic the entry reproduces.  The Python host (vit_amd/engine.py) binds these with ctypes
- * (see INTEGRATION.md).
+ * one of those torch calls (forward) or its autograd counterpart run by
+ * `scaler.scale(loss).backward()` (train_vit.py:939); the cited file:line is the reference (or
+ * torch) call site whose arithmetic the entry reproduces.  The Python host (vit_amd/engine.py)
+ * binds these with ctypes.
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller; the library borrows it for the
@@ -12,7 +13,9 @@
  *   - `stream` is a hipStream_t (NULL = the default stream); calls only enqueue work;
  *   - return value 0 = ok, negative = RVIT_E*; rvit_last_error() returns a thread-local text;
  *   - dtype codes: RVIT_BF16 = 0, RVIT_F32 = 1; activation codes RVIT_ACT_*;
- *   - bf16 tensors are raw 16-bit words (torch.bfloat16 storage), row-major, pitches in ELEMENTS.
+ *   - bf16 tensors are raw 16-bit words (torch.bfloat16 storage), row-major, pitches in ELEMENTS;
+ *   - "row remap (g, e)": logical row m maps to physical row (m / g) * (g + e) + m % g + e when
+ *     g > 0 (the patch rows of the token stream, which skip the cls row of every sample).
  */
 #ifndef RVIT_H
 #define RVIT_H
@@ -21,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 1
+#define RVIT_ABI_VERSION 2
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -29,6 +32,9 @@ extern "C" {
 #define RVIT_ACT_NONE 0
 #define RVIT_ACT_RELU 1
 #define RVIT_ACT_GELU 2 /* exact erf form, nn.GELU() / activation='gelu' */
+
+#define RVIT_GATE_GELU_GRAD 1 /* value *= gelu'(gate)   (backward of nn.GELU) */
+#define RVIT_GATE_RELU_MASK 2 /* value *= (gate > 0)    (backward of ReLU)    */
 
 #define RVIT_OK 0
 #define RVIT_EINVAL (-1)
@@ -38,21 +44,24 @@ extern "C" {
 int rvit_version(void);
 const char* rvit_last_error(void);
 
-/* C[M,N] = act( scale[n] * (A[M,K] . B[N,K]^T) + bias[n] + R ) on bf16 MFMA, fp32 accumulate.
- * Replaces every nn.Linear on the path: packed QKV in-proj (torch functional.py:5819-5833),
+/* C[M,N] = act( gate( scale[n] * (A[M,K] . B[N,K]^T) + bias[n] ) + R ) on bf16 MFMA, fp32 accumulate.
+ * Forward: every nn.Linear on the path — packed QKV in-proj (torch functional.py:5819-5833),
  * attention out-proj + residual (functional.py:6632-6637, transformer.py:947-949), linear1+GELU
  * and linear2+residual (transformer.py:980-982), the head Linears (train_vit.py:122-127), and the
  * 1x1 patch_embed conv with the flatten/transpose/cls-offset/pos_embed add folded into the
- * epilogue (train_vit.py:93,149-159).
- *   A: bf16 [M,lda]   B: bf16 [N,ldb] (nn.Linear weight layout)   K % 8 == 0
+ * epilogue (train_vit.py:93,149-159).  Backward: the input-gradient of the same Linears
+ * (B = the transposed weight), with the GELU derivative applied through `gate`.
+ *   A: bf16 [.,lda], optional row remap (a_row_group, a_row_extra)   B: bf16 [N,ldb]   K % 8 == 0
  *   C: bf16 or f32 [.,ldc];  preact (optional, bf16 [.,ldp]) receives the value before R/act
+ *   gate: optional bf16 [.,ldg] indexed like C, gate_mode RVIT_GATE_*
  *   R: optional residual (bf16 or f32), row = m % r_period when r_period > 0, else the C row
- *   row_group > 0 remaps the output row: (m / g) * (g + row_extra) + m % g + row_extra
+ *   row remap (row_group, row_extra) applies to C, preact, gate and R
  *   tile: 0 = automatic tile choice, 1/2/3 force 256x64 / 128x64 / 64x64 (testing). */
-int rvit_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype,
-                   int64_t M, int N, int K, const float* scale, const float* bias, const void* R, int64_t ldr,
-                   int r_dtype, int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra,
-                   int tile, void* stream);
+int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra, const void* B, int64_t ldb, void* C,
+                   int64_t ldc, int c_dtype, int64_t M, int N, int K, const float* scale, const float* bias,
+                   const void* gate, int64_t ldg, int gate_mode, const void* R, int64_t ldr, int r_dtype,
+                   int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra, int tile,
+                   void* stream);
 
 /* NHWC implicit-GEMM convolution, bf16 MFMA: y = act( scale[c]*conv(x, w) + bias[c] + residual ).
  * Replaces the timm resnet18 feature extractor convs + (eval-mode, folded) BatchNorm + ReLU +
@@ -65,6 +74,14 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
                          int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* scale,
                          const float* bias, const void* residual, int act, int tile, void* stream);
 
+/* Input gradient of the convolution above (autograd of the stem convs): dx = conv_transpose(dy, w)
+ * (+ residual, the gradient arriving over the other branch of a BasicBlock).
+ *   dy: bf16 [B,Hy,Wy,Cout]; w_t: bf16 [Cin, KH, KW, Cout]; dx/residual: bf16 [B,Hx,Wx,Cin];
+ *   stride 1 or 2; Cout % 64 == 0. */
+int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int KH, int KW,
+                           int stride, int pad, int Hx, int Wx, int Cin, const void* residual, int tile,
+                           void* stream);
+
 /* Patch-embedding convolution straight into the token stream (pure-ViT `patch16` layout; the
  * same flatten/transpose/cls-offset/pos_embed epilogue as the 1x1 case, train_vit.py:149-159):
  * tokens[b, 1+p, :] = conv(x, w)[b, p, :] + bias + pos_embed[1+p, :], fp32 [B, Ho*Wo+1, Cout].
@@ -72,6 +89,19 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
 int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* bias,
                            const float* pos_embed, int tile, void* stream);
+
+/* Weight gradient of a Linear: dW[N_store,K] += dY[M,N]^T . X[M,K] (fp32 atomics, accumulates like
+ * autograd's .grad).  dY: bf16 [.,ldy], X: bf16 [.,ldx], optional row remaps; N, K, ldy, ldx
+ * multiples of 8; rows n >= N_store of the product are discarded (padded logits).
+ * splits: number of M partitions (0 = automatic). */
+int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extra, const void* X, int64_t ldx,
+                    int x_row_group, int x_row_extra, float* dW, int64_t ldw, int64_t M, int N, int N_store, int K,
+                    int splits, void* stream);
+
+/* Weight gradient of the NHWC convolution: dW[Cout, KH*KW*seg_len] += dy^T . gather(x), same
+ * geometry arguments and weight layout as rvit_conv2d_fwd_bf16. */
+int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int H, int W, int Cpix, int seg_len,
+                           int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, int splits, void* stream);
 
 /* fp32 NCHW image batch -> zero-haloed bf16 NHWC4 (channel 3 = 0).  Input contract of
  * CNNViTHybrid.forward (train_vit.py:141-146: x is [B,3,224,224] float).  Writes only the
@@ -93,12 +123,42 @@ int rvit_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gam
                        int y_dtype, int64_t ldy, float* mean, float* rstd, int64_t rows, int E, float eps,
                        void* stream);
 
+/* LayerNorm backward fused with the residual-gradient accumulation of the pre-LN block
+ * (x + f(LN(x)), torch transformer.py:947-950):  dx (+)= LN'(dy); dgamma += ..., dbeta += ...
+ *   dy: bf16 [rows,lddy]; x: f32 [rows,ldx] (the LN input); mean/rstd from the forward;
+ *   dx: f32 [rows,lddx], accumulate != 0 adds to its content; dx_bf16: optional bf16 copy of the
+ *   updated dx; dgamma/dbeta: f32 [E], accumulated with atomics. */
+int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                       const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
+                       void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* stream);
+
 /* softmax(q k^T * scale) v per (batch, head), head_dim 64, S <= 256, no mask
  * (torch functional.py:6623-6631 -> scaled_dot_product_attention).
  *   qkv: bf16 [B*S, ldq] holding q | k | v column blocks of width H*64 (the in-proj output);
  *   out: bf16 [B*S, ldo], head h at columns h*64..; lse (optional) fp32 [B,H,S]. */
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
                   void* stream);
+
+/* Backward of rvit_attn_fwd: dqkv (same layout as qkv) from qkv, out, dout and the saved lse. */
+int rvit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
+                  int H, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, void* stream);
+
+/* Cross-entropy with label smoothing, mean over the batch, value and gradient in one pass
+ * (nn.CrossEntropyLoss(label_smoothing=...), train_vit.py:894,937).
+ *   logits f32 [B,ldl]; labels int64 [B]; *loss_sum += mean loss (caller zeroes it);
+ *   dlogits (optional) f32 [B,lddl]; dlogits_bf16 (optional) bf16 [B,lddb] with columns C..C_pad-1
+ *   zero-filled (operand of the head's backward GEMMs); both scaled by grad_scale. */
+int rvit_ce_loss(const float* logits, int64_t ldl, const int64_t* labels, float* loss_sum, float* dlogits,
+                 int64_t lddl, void* dlogits_bf16, int64_t lddb, int B, int C, int C_pad, float label_smoothing,
+                 float grad_scale, void* stream);
+
+/* out[n] += sum_m a[m,n]  (bias gradients); a bf16 [.,lda] with optional row remap. */
+int rvit_colsum_bf16(const void* a, int64_t lda, float* out, int64_t M, int N, int64_t row_group, int64_t row_extra,
+                     void* stream);
+
+/* out[j] += sum_b x[b*ldb + j], j < n  (pos_embed / cls_token gradients: token gradients summed
+ * over the batch; backward of the broadcast add at train_vit.py:155-159). */
+int rvit_batch_sum_f32(const float* x, int64_t ldb, float* out, int B, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

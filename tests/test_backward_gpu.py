@@ -1,0 +1,220 @@
+"""GPU parity of the backward / loss kernels against torch autograd (fp32, CPU) on the same
+bf16-rounded inputs.  Tolerances: fp32-accumulated results 1e-3 relative to the gradient scale;
+bf16 outputs one bf16 ulp (2^-7 relative) plus the attention-specific P rounding."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _close(got, ref, rtol, atol, what=""):
+    got = got.float().cpu()
+    ref = ref.float()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = (err > bound).sum().item()
+    assert bad == 0, f"{what}: {bad}/{err.numel()} out of tolerance, max err {err.max().item():.4g} " \
+                     f"(ref scale {ref.abs().max().item():.3g})"
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(1000, 256, 256, 0), (777, 768, 264, 3), (64, 16, 128, 1), (5000, 1024, 256, 0),
+                                          (300, 136, 72, 2)])
+def test_wgrad_plain(dev, M, N, K, splits):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = _bf(torch.randn(M, N, generator=g))
+    x = _bf(torch.randn(M, K, generator=g))
+    init = torch.randn(N, K, generator=g)
+    dw = init.clone().to(dev)
+    ops.wgrad(dy.to(dev), x.to(dev), dw, splits=splits)
+    ref = init + dy.float().T @ x.float()
+    _close(dw, ref, 1e-3, 1e-3 * math.sqrt(M), "wgrad")
+
+
+def test_wgrad_exact_asymmetric(dev):
+    """Small integers: every product and sum is exact, so any layout/permutation error shows."""
+    from vit_amd import ops
+    M, N, K = 256, 128, 128
+    dy = _bf((torch.arange(M * N).reshape(M, N) % 7 - 3).float())
+    x = _bf((torch.arange(M * K).reshape(M, K) % 5 - 2).float())
+    dw = torch.zeros(N, K, device=dev)
+    ops.wgrad(dy.to(dev), x.to(dev), dw, splits=2)
+    assert torch.equal(dw.cpu(), dy.float().T @ x.float())
+
+
+def test_wgrad_padded_logits_and_row_remap(dev):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, C, K = 37, 11, 128
+    dl = torch.zeros(B, 16)
+    dl[:, :C] = torch.randn(B, C, generator=g)
+    dl = _bf(dl)
+    h = _bf(torch.randn(B, K, generator=g))
+    dw = torch.zeros(C, K, device=dev)
+    ops.wgrad(dl.to(dev), h.to(dev), dw, n_store=C)
+    _close(dw, dl[:, :C].float().T @ h.float(), 1e-3, 1e-3, "head wgrad")
+    # patch_embed wgrad: dY = token gradients (rows past the cls row), X = stem features
+    Bq, P, E, Cf = 3, 49, 64, 128
+    dtok = _bf(torch.randn(Bq * (P + 1), E, generator=g))
+    feat = _bf(torch.randn(Bq * P, Cf, generator=g))
+    dwp = torch.zeros(E, Cf, device=dev)
+    ops.wgrad(dtok.to(dev), feat.to(dev), dwp, rows=Bq * P, y_row_group=P, y_row_extra=1)
+    ref = dtok.float().reshape(Bq, P + 1, E)[:, 1:].reshape(-1, E).T @ feat.float()
+    _close(dwp, ref, 1e-3, 2e-2, "patch wgrad")
+
+
+@pytest.mark.parametrize("cin,cout,hw,k,stride,pad", [(64, 64, 56, 3, 1, 1), (64, 128, 56, 3, 2, 1), (64, 128, 56, 1, 2, 0),
+                                                      (256, 512, 14, 3, 2, 1), (128, 128, 28, 3, 1, 1)])
+def test_conv_wgrad_and_dgrad(dev, cin, cout, hw, k, stride, pad):
+    from vit_amd import ops
+    B = 2
+    g = torch.Generator().manual_seed(cin + cout + hw + k)
+    x = _bf(torch.randn(B, hw, hw, cin, generator=g))
+    w = _bf(torch.randn(cout, k, k, cin, generator=g) / math.sqrt(k * k * cin))
+    ho = (hw + 2 * pad - k) // stride + 1
+    dy = _bf(torch.randn(B, ho, ho, cout, generator=g))
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.float().permute(0, 3, 1, 2).requires_grad_(True)
+    y = F.conv2d(xr, wr, None, stride, pad)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    dw = torch.zeros(cout, k * k * cin, device=dev)
+    ops.conv2d_wgrad(dy.to(dev), x.to(dev), dw, kh=k, kw=k, stride=stride, pad=pad)
+    _close(dw.reshape(cout, k, k, cin), wr.grad.permute(0, 2, 3, 1), 2e-3, 2e-2, "conv wgrad")
+    w_t = w.permute(3, 1, 2, 0).reshape(cin, k * k * cout).contiguous()
+    res = _bf(torch.randn(B, hw, hw, cin, generator=g))
+    dx = torch.empty(B, hw, hw, cin, dtype=torch.bfloat16, device=dev)
+    ops.conv2d_dgrad(dy.to(dev), w_t.to(dev), dx, kh=k, kw=k, stride=stride, pad=pad, residual=res.to(dev))
+    _close(dx, xr.grad.permute(0, 2, 3, 1) + res.float(), 1.0 / 128, 2e-2, "conv dgrad")
+
+
+def test_conv1_wgrad_px4(dev):
+    from vit_amd import ops
+    B, H = 2, 224
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 3, H, H, generator=g)
+    xp = torch.zeros(B, H + 6, H + 8, 4, dtype=torch.bfloat16, device=dev)
+    ops.input_pack(x.to(dev), xp, 3, 3)
+    dy = _bf(torch.randn(B, 112, 112, 64, generator=g))
+    wr = torch.zeros(64, 3, 7, 7, requires_grad=True)
+    F.conv2d(_bf(x).float(), wr, None, 2, 3).backward(dy.float().permute(0, 3, 1, 2))
+    dw = torch.zeros(64, 224, device=dev)
+    ops.conv2d_wgrad(dy.to(dev), xp, dw, kh=7, kw=1, stride=2, pad=0, seg_len=32)
+    got = dw.reshape(64, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2)
+    _close(got, wr.grad, 2e-3, 5e-2, "conv1 wgrad")
+
+
+@pytest.mark.parametrize("rows,E", [(300, 256), (1000, 768), (7, 384)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_layernorm_bwd(dev, rows, E, accumulate):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(rows + E)
+    x = torch.randn(rows, E, generator=g) * 2 + 0.3
+    gam = torch.randn(E, generator=g)
+    bet = torch.randn(E, generator=g)
+    dy = _bf(torch.randn(rows, E, generator=g))
+    base = torch.randn(rows, E, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gr = gam.clone().requires_grad_(True)
+    br = bet.clone().requires_grad_(True)
+    F.layer_norm(xr, (E,), gr, br, 1e-5).backward(dy.float())
+    mean = x.mean(1)
+    rstd = 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+    dx = base.clone().to(dev)
+    dxb = torch.empty(rows, E, dtype=torch.bfloat16, device=dev)
+    dg = torch.zeros(E, device=dev)
+    db = torch.zeros(E, device=dev)
+    ops.layernorm_bwd(dy.to(dev), x.to(dev), mean.to(dev), rstd.to(dev), gam.to(dev), dx, dg, db,
+                      accumulate=accumulate, dx_bf16=dxb)
+    ref = xr.grad + (base if accumulate else 0)
+    _close(dx, ref, 1e-4, 1e-4, "ln dx")
+    _close(dxb, ref, 1.0 / 128, 1e-3, "ln dx bf16")
+    _close(dg, gr.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln dgamma")
+    _close(db, br.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln dbeta")
+
+
+@pytest.mark.parametrize("B,S,H", [(3, 50, 4), (2, 197, 3), (4, 17, 2), (1, 64, 1), (2, 100, 2), (1, 256, 1)])
+def test_attention_bwd(dev, B, S, H):
+    from vit_amd import ops
+    E = H * 64
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    qkv = _bf(torch.randn(B * S, 3 * E, generator=g))
+    dout = _bf(torch.randn(B * S, E, generator=g))
+    qkv_r = qkv.float().requires_grad_(True)
+    q, k, v = [t.reshape(B, S, H, 64).transpose(1, 2) for t in qkv_r.split(E, dim=1)]
+    o = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B * S, E)
+    o.backward(dout.float())
+    out = torch.empty(B * S, E, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B, H, S, device=dev)
+    qd = qkv.to(dev)
+    ops.attention(qd, out, B, S, H, lse=lse)
+    dqkv = torch.zeros(B * S, 3 * E, dtype=torch.bfloat16, device=dev)
+    ops.attention_bwd(qd, out, dout.to(dev), lse, dqkv, B, S, H)
+    ref = qkv_r.grad
+    scale = ref.abs().max().item()
+    _close(dqkv, ref, 1.0 / 32, 0.02 * scale, "attention dqkv")
+    # relative Frobenius error: the per-element bound above is loose, this one is not
+    rel = (dqkv.float().cpu() - ref).norm() / ref.norm()
+    assert rel < 0.02, f"attention backward relative error {rel:.4f}"
+
+
+def test_ce_loss(dev):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, C = 300, 11
+    z = torch.randn(B, C, generator=g) * 3
+    y = torch.randint(0, C, (B,), generator=g)
+    zr = z.clone().requires_grad_(True)
+    loss = F.cross_entropy(zr, y, label_smoothing=0.05)
+    loss.backward()
+    ls = torch.zeros(1, device=dev)
+    dl = torch.empty(B, C, device=dev)
+    dlb = torch.full((B, 16), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.ce_loss(z.to(dev), y.to(dev), ls, dl, dlb, 0.05, grad_scale=1.0 / B)
+    _close(ls, loss.detach().reshape(1), 1e-5, 1e-5, "loss")
+    _close(dl, zr.grad, 1e-4, 1e-7, "dlogits")
+    _close(dlb[:, :C], zr.grad, 1.0 / 128, 1e-6, "dlogits bf16")
+    assert float(dlb[:, C:].abs().sum()) == 0.0
+
+
+def test_colsum_and_batch_sum(dev):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(6)
+    a = _bf(torch.randn(1234, 200, generator=g))
+    out = torch.ones(200, device=dev)
+    ops.colsum(a.to(dev), out)
+    _close(out, 1 + a.float().sum(0), 1e-4, 1e-3, "colsum")
+    x = torch.randn(9, 50 * 64, generator=g)
+    o2 = torch.ones(50 * 64, device=dev)
+    ops.batch_sum(x.to(dev), o2)
+    _close(o2, 1 + x.sum(0), 1e-5, 1e-5, "batch_sum")
+
+
+def test_gemm_gate_and_a_remap(dev):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 150, 512, 128
+    dy = _bf(torch.randn(M, K, generator=g))
+    wt = _bf(torch.randn(N, K, generator=g) / 8)
+    u = _bf(torch.randn(M, N, generator=g))
+    ur = u.float().requires_grad_(True)
+    F.gelu(ur).backward(dy.float() @ wt.float().T)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ops.gemm(dy.to(dev), wt.to(dev), out, gate=u.to(dev), gate_mode="gelu_grad")
+    _close(out, ur.grad, 1.0 / 128, 2e-3, "gelu-grad gate")
+    ops.gemm(dy.to(dev), wt.to(dev), out, gate=u.to(dev), gate_mode="relu_mask")
+    _close(out, (dy.float() @ wt.float().T) * (u.float() > 0), 1.0 / 128, 2e-3, "relu-mask gate")
+    # A rows taken past the cls row of every sample
+    B, P, E = 4, 49, 64
+    tok = _bf(torch.randn(B * (P + 1), E, generator=g))
+    w2 = _bf(torch.randn(128, E, generator=g) / 8)
+    o2 = torch.empty(B * P, 128, dtype=torch.float32, device=dev)
+    ops.gemm(tok.to(dev), w2.to(dev), o2, a_rows=B * P, a_row_group=P, a_row_extra=1)
+    ref = tok.float().reshape(B, P + 1, E)[:, 1:].reshape(-1, E) @ w2.float().T
+    _close(o2, ref, 1e-4, 1e-4, "A row remap")

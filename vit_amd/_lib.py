@@ -18,31 +18,36 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 1
+GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
+ABI_VERSION = 2
 
 
 class RvitError(RuntimeError):
     """A librvit entry point returned a non-zero status."""
 
 
-# name -> argtypes, exactly mirroring include/rvit.h (tests/test_abi.py cross-checks the header)
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> (argtypes, restype), exactly mirroring include/rvit.h (tests/test_abi.py cross-checks it)
 SIGNATURES = {
     "rvit_version": ([], c_int),
     "rvit_last_error": ([], c_char_p),
-    "rvit_gemm_bf16": ([c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_int, c_int,
-                        c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_int,
-                        c_int, c_int, c_void_p], c_int),
-    "rvit_conv2d_fwd_bf16": ([c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p, c_void_p,
-                             c_int, c_int, c_void_p], c_int),
-    "rvit_conv2d_tokens_fwd": ([c_void_p, c_void_p, c_void_p] + [c_int] * 12 + [c_void_p, c_void_p, c_int, c_void_p],
-                               c_int),
-    "rvit_input_pack_nhwc4": ([c_void_p, c_void_p] + [c_int] * 8 + [c_void_p], c_int),
-    "rvit_maxpool3x3s2_nhwc": ([c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p], c_int),
-    "rvit_embed_cls": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p], c_int),
-    "rvit_layernorm_fwd": ([c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p,
-                            c_void_p, c_int64, c_int, c_float, c_void_p], c_int),
-    "rvit_attn_fwd": ([c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p],
-                      c_int),
+    "rvit_gemm_bf16": ([P, L, I, I, P, L, P, L, I, L, I, I, P, P, P, L, I, P, L, I, I, I, P, L, I, I, I, P], c_int),
+    "rvit_conv2d_fwd_bf16": ([P, P, P] + [I] * 12 + [P, P, P, I, I, P], c_int),
+    "rvit_conv2d_dgrad_bf16": ([P, P, P] + [I] * 11 + [P, I, P], c_int),
+    "rvit_conv2d_tokens_fwd": ([P, P, P] + [I] * 12 + [P, P, I, P], c_int),
+    "rvit_wgrad_bf16": ([P, L, I, I, P, L, I, I, P, L, L, I, I, I, I, P], c_int),
+    "rvit_conv2d_wgrad_bf16": ([P, P, P] + [I] * 12 + [I, P], c_int),
+    "rvit_input_pack_nhwc4": ([P, P] + [I] * 8 + [P], c_int),
+    "rvit_maxpool3x3s2_nhwc": ([P, P, P] + [I] * 4 + [P], c_int),
+    "rvit_embed_cls": ([P, P, P, I, I, I, P], c_int),
+    "rvit_layernorm_fwd": ([P, I, L, P, P, P, I, L, P, P, L, I, F, P], c_int),
+    "rvit_layernorm_bwd": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P], c_int),
+    "rvit_attn_fwd": ([P, P, P, I, I, I, L, L, F, P], c_int),
+    "rvit_attn_bwd": ([P, P, P, P, P, I, I, I, L, L, L, L, F, P], c_int),
+    "rvit_ce_loss": ([P, L, P, P, P, L, P, L, I, I, I, F, F, P], c_int),
+    "rvit_colsum_bf16": ([P, L, P, L, I, L, L, P], c_int),
+    "rvit_batch_sum_f32": ([P, L, P, I, L, P], c_int),
 }
 
 _lib = None

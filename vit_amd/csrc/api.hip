@@ -1,5 +1,5 @@
 // extern "C" surface of librvit (declared in include/rvit.h).  Argument validation lives in the
-// *_impl functions next to each kernel; this file only adapts ABI types.
+// *_impl / *_dispatch functions next to each kernel; this file only adapts ABI types.
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -18,33 +18,48 @@ void rvit_set_error(const char* fmt, ...) {
 
 static inline bool aligned_to(const void* p, uintptr_t a) { return (((uintptr_t)p) & (a - 1)) == 0; }
 
+static void conv_geometry(GemmArgs& a, const void* x, const void* w, int B, int H, int W, int Cpix, int seg_len, int KH,
+                          int KW, int stride, int pad, int Ho, int Wo, int Cout) {
+  a.A = (const bf16*)x; a.lda = 0;
+  a.B = (const bf16*)w; a.ldb = (long)KH * KW * seg_len;
+  a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * seg_len;
+  a.mode = 1;
+  a.H = H; a.W = W; a.Cpix = Cpix; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.seg_len = seg_len;
+}
+
 extern "C" {
 
 int rvit_version(void) { return RVIT_ABI_VERSION; }
 const char* rvit_last_error(void) { return g_err; }
 
-int rvit_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int c_dtype,
-                   int64_t M, int N, int K, const float* scale, const float* bias, const void* R, int64_t ldr,
-                   int r_dtype, int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra,
-                   int tile, void* stream) {
+int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra, const void* B, int64_t ldb, void* C,
+                   int64_t ldc, int c_dtype, int64_t M, int N, int K, const float* scale, const float* bias,
+                   const void* gate, int64_t ldg, int gate_mode, const void* R, int64_t ldr, int r_dtype,
+                   int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra, int tile,
+                   void* stream) {
   GemmArgs a{};
-  a.A = (const bf16*)A; a.lda = lda;
+  a.A = (const bf16*)A; a.lda = lda; a.a_row_group = a_row_group; a.a_row_extra = a_row_extra;
   a.B = (const bf16*)B; a.ldb = ldb;
   a.M = M; a.N = N; a.K = K;
   a.mode = 0;
   a.C = C; a.ldc = ldc; a.c_f32 = c_dtype == RVIT_F32;
   a.C2 = (bf16*)preact; a.ldc2 = ldp;
   a.scale = scale; a.bias = bias;
+  a.G = (const bf16*)gate; a.ldg = ldg; a.gate = gate ? gate_mode : 0;
   a.R = R; a.ldr = ldr; a.r_f32 = r_dtype == RVIT_F32; a.r_period = r_period;
   a.act = act; a.row_group = row_group; a.row_extra = row_extra; a.tile = tile;
   RVIT_CHECK_ARG(c_dtype == RVIT_BF16 || c_dtype == RVIT_F32, "gemm: bad c_dtype %d", c_dtype);
   RVIT_CHECK_ARG(act >= 0 && act <= 2, "gemm: bad act %d", act);
+  RVIT_CHECK_ARG(!gate || gate_mode == RVIT_GATE_GELU_GRAD || gate_mode == RVIT_GATE_RELU_MASK, "gemm: bad gate mode");
   RVIT_CHECK_ARG(ldc >= N && (!R || ldr >= N) && (!preact || ldp >= N), "gemm: output pitch smaller than N");
-  RVIT_CHECK_ARG(row_group >= 0 && row_extra >= 0 && r_period >= 0, "gemm: negative row remap");
+  RVIT_CHECK_ARG(row_group >= 0 && row_extra >= 0 && r_period >= 0 && a_row_group >= 0 && a_row_extra >= 0,
+                 "gemm: negative row remap");
   // vector epilogue: 8 consecutive columns per lane, 16-byte accesses
   bool vec = (N & 7) == 0 && (ldc & (a.c_f32 ? 3 : 7)) == 0 && aligned_to(C, 16);
   if (scale) vec = vec && aligned_to(scale, 16);
   if (bias) vec = vec && aligned_to(bias, 16);
+  if (gate) vec = vec && (ldg & 7) == 0 && aligned_to(gate, 16);
   if (R) vec = vec && (ldr & (a.r_f32 ? 3 : 7)) == 0 && aligned_to(R, 16);
   if (preact) vec = vec && (ldp & 7) == 0 && aligned_to(preact, 16);
   a.vec = vec;
@@ -60,12 +75,7 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
   RVIT_CHECK_ARG((Ho - 1) * stride - pad + KH - 1 < H + pad + stride && (Wo - 1) * stride - pad < W,
                  "conv: output size inconsistent with input");
   GemmArgs a{};
-  a.A = (const bf16*)x; a.lda = 0;
-  a.B = (const bf16*)w; a.ldb = (long)KH * KW * seg_len;
-  a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * seg_len;
-  a.mode = 1;
-  a.H = H; a.W = W; a.Cpix = Cpix; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
-  a.seg_len = seg_len;
+  conv_geometry(a, x, w, B, H, W, Cpix, seg_len, KH, KW, stride, pad, Ho, Wo, Cout);
   a.C = y; a.ldc = Cout; a.c_f32 = 0;
   a.scale = scale; a.bias = bias;
   a.R = residual; a.ldr = Cout; a.r_f32 = 0; a.r_period = 0;
@@ -79,6 +89,23 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int KH, int KW,
+                           int stride, int pad, int Hx, int Wx, int Cin, const void* residual, int tile,
+                           void* stream) {
+  RVIT_CHECK_ARG(B > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && KH > 0 && KW > 0 && pad >= 0, "conv dgrad: bad geometry");
+  RVIT_CHECK_ARG((long)B * Hy * Wy < 0x7fffffffL && (long)B * Hx * Wx < 0x7fffffffL, "conv dgrad: too many pixels");
+  RVIT_CHECK_ARG((Cout & 63) == 0, "conv dgrad: Cout=%d must be a multiple of 64", Cout);
+  GemmArgs a{};
+  // rows = pixels of dX, K = (kh, kw, cout) runs of dY pixels, N = Cin
+  conv_geometry(a, dy, w_t, B, Hy, Wy, Cout, Cout, KH, KW, stride, pad, Hx, Wx, Cin);
+  a.transposed = 1;
+  a.C = dx; a.ldc = Cin; a.c_f32 = 0;
+  a.R = residual; a.ldr = Cin; a.r_f32 = 0;
+  a.tile = tile;
+  a.vec = (Cin & 7) == 0 && aligned_to(dx, 16) && (!residual || aligned_to(residual, 16));
+  return rvit_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* bias,
                            const float* pos_embed, int tile, void* stream) {
@@ -87,12 +114,7 @@ int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, i
   RVIT_CHECK_ARG((long)B * H * W < 0x7fffffffL, "conv_tokens: B*H*W exceeds 2^31 pixels");
   RVIT_CHECK_ARG(tokens && pos_embed, "conv_tokens: null pointer");
   GemmArgs a{};
-  a.A = (const bf16*)x; a.lda = 0;
-  a.B = (const bf16*)w; a.ldb = (long)KH * KW * seg_len;
-  a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * seg_len;
-  a.mode = 1;
-  a.H = H; a.W = W; a.Cpix = Cpix; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
-  a.seg_len = seg_len;
+  conv_geometry(a, x, w, B, H, W, Cpix, seg_len, KH, KW, stride, pad, Ho, Wo, Cout);
   a.C = tokens; a.ldc = Cout; a.c_f32 = 1;
   a.bias = bias;
   a.R = pos_embed + Cout; a.ldr = Cout; a.r_f32 = 1; a.r_period = Ho * Wo;
@@ -102,6 +124,33 @@ int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, i
   if (bias) vec = vec && aligned_to(bias, 16);
   a.vec = vec;
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
+}
+
+int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extra, const void* X, int64_t ldx,
+                    int x_row_group, int x_row_extra, float* dW, int64_t ldw, int64_t M, int N, int N_store, int K,
+                    int splits, void* stream) {
+  WgradArgs a{};
+  a.dY = (const bf16*)dY; a.ldy = ldy; a.y_row_group = y_row_group; a.y_row_extra = y_row_extra;
+  a.X = (const bf16*)X; a.ldx = ldx; a.x_row_group = x_row_group; a.x_row_extra = x_row_extra;
+  a.dW = dW; a.ldw = ldw; a.M = M; a.N = N; a.N_store = N_store; a.K = K; a.mode = 0; a.splits = splits;
+  return rvit_wgrad_dispatch(a, (hipStream_t)stream);
+}
+
+int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int H, int W, int Cpix, int seg_len,
+                           int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, int splits,
+                           void* stream) {
+  RVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+                 "conv wgrad: bad geometry");
+  RVIT_CHECK_ARG((long)B * H * W < 0x7fffffffL && (long)B * Ho * Wo < 0x7fffffffL, "conv wgrad: too many pixels");
+  WgradArgs a{};
+  a.dY = (const bf16*)dy; a.ldy = Cout;
+  a.X = (const bf16*)x; a.ldx = 0;
+  a.dW = dW; a.ldw = (long)KH * KW * seg_len;
+  a.M = (long)B * Ho * Wo; a.N = Cout; a.N_store = Cout; a.K = KH * KW * seg_len;
+  a.mode = 1;
+  a.H = H; a.W = W; a.Cpix = Cpix; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.seg_len = seg_len; a.splits = splits;
+  return rvit_wgrad_dispatch(a, (hipStream_t)stream);
 }
 
 int rvit_input_pack_nhwc4(const float* x_nchw, void* out, int B, int C, int H, int W, int Hp, int Wp, int pad_top,
@@ -124,9 +173,37 @@ int rvit_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gam
                                  rows, E, eps, (hipStream_t)stream);
 }
 
+int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                       const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
+                       void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* stream) {
+  return rvit_layernorm_bwd_impl(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, accumulate, dx_bf16, lddb, dgamma,
+                                 dbeta, rows, E, (hipStream_t)stream);
+}
+
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
                   void* stream) {
   return rvit_attn_fwd_impl(qkv, out, lse, B, S, H, ldq, ldo, scale, (hipStream_t)stream);
+}
+
+int rvit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
+                  int H, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, void* stream) {
+  return rvit_attn_bwd_impl(qkv, out, dout, lse, dqkv, B, S, H, ldq, ldo, lddo, lddq, scale, (hipStream_t)stream);
+}
+
+int rvit_ce_loss(const float* logits, int64_t ldl, const int64_t* labels, float* loss_sum, float* dlogits,
+                 int64_t lddl, void* dlogits_bf16, int64_t lddb, int B, int C, int C_pad, float label_smoothing,
+                 float grad_scale, void* stream) {
+  return rvit_ce_loss_impl(logits, ldl, (const long*)labels, loss_sum, dlogits, lddl, dlogits_bf16, lddb, B, C, C_pad,
+                           label_smoothing, grad_scale, (hipStream_t)stream);
+}
+
+int rvit_colsum_bf16(const void* a, int64_t lda, float* out, int64_t M, int N, int64_t row_group, int64_t row_extra,
+                     void* stream) {
+  return rvit_colsum_impl(a, lda, out, M, N, row_group, row_extra, (hipStream_t)stream);
+}
+
+int rvit_batch_sum_f32(const float* x, int64_t ldb, float* out, int B, int64_t n, void* stream) {
+  return rvit_batch_sum_impl(x, ldb, out, B, n, (hipStream_t)stream);
 }
 
 }  // extern "C"

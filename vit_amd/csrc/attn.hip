@@ -178,6 +178,273 @@ int launch_attn_fwd(const bf16* qkv, bf16* out, float* lse, int B, int S, int H,
   return RVIT_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward (autograd of scaled_dot_product_attention, run by train_vit.py:939).  P is recomputed
+// from q, k and the forward's log-sum-exp.  Everything of one (batch, head) — Q, K, V, dO — sits
+// in LDS in ONE image per tensor that serves both row reads (ds_read_b128) and transposing reads
+// (ds_read_b64_tr_b16) conflict-free: 128-byte rows, chunk ^= bitreverse3((row>>1)&7).
+//   pass A: a wave owns 32 keys (key on the MFMA lane), sweeps the query blocks:
+//           S = Q K^T, dP = dO V^T -> P, dS in registers -> dV^T += dO^T P, dK^T += Q^T dS
+//           (the accumulator tiles are used directly as B operands, no LDS round trip)
+//   pass B: a wave owns 32 queries (query on the lane), sweeps the key blocks:
+//           S^T, dP^T recomputed -> dS^T -> dQ^T += K^T dS^T
+// No cross-wave reduction and no atomics: dq, dk, dv are bitwise reproducible.
+__device__ __forceinline__ int du_off(int row, int ch) {
+  const int g = (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1);
+  return row * 128 + ((ch ^ g) << 4);
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+                                                       const bf16* __restrict__ dO, const float* __restrict__ lse,
+                                                       bf16* __restrict__ dqkv, int total_pairs, int S, int H,
+                                                       long ldq, long ldo, long lddo, long lddq, float scale) {
+  constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
+  constexpr int SP = 32 * NKB;
+  constexpr int TILE = SP * 128;
+  constexpr int PAIR_BYTES = 4 * TILE + SP * 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int E = H * 64;
+  const int pair0 = blockIdx.x * PAIRS;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const float c_l2 = scale * 1.44269504088896340736f;
+
+  // ---- stage Q, K, V, dO; delta = rowsum(dO * O); lse (padded queries: +inf -> P = 0) ------------
+#pragma unroll
+  for (int pi = 0; pi < PAIRS; ++pi) {
+    const int pair = pair0 + pi;
+    const bool pv = pair < total_pairs;
+    const int b = pv ? pair / H : 0, h = pv ? pair % H : 0;
+    char* sQ = smem + pi * PAIR_BYTES;
+    char* sK = sQ + TILE;
+    char* sV = sK + TILE;
+    char* sD = sV + TILE;
+    float* sLse = reinterpret_cast<float*>(sD + TILE);
+    float* sDel = sLse + SP;
+    for (int id = t; id < SP * 8; id += 256) {
+      const int row = id >> 3, c = id & 7;
+      const bool ok = pv && row < S;
+      const long tok = (long)b * S + row;
+      const bf16* qp = qkv + tok * ldq + h * 64 + c * 8;
+      const uint4 qv = ok ? *reinterpret_cast<const uint4*>(qp) : zero4;
+      const uint4 kv = ok ? *reinterpret_cast<const uint4*>(qp + E) : zero4;
+      const uint4 vv = ok ? *reinterpret_cast<const uint4*>(qp + 2 * E) : zero4;
+      const uint4 dv = ok ? *reinterpret_cast<const uint4*>(dO + tok * lddo + h * 64 + c * 8) : zero4;
+      const uint4 ov = ok ? *reinterpret_cast<const uint4*>(O + tok * ldo + h * 64 + c * 8) : zero4;
+      const int o = du_off(row, c);
+      *reinterpret_cast<uint4*>(sQ + o) = qv;
+      *reinterpret_cast<uint4*>(sK + o) = kv;
+      *reinterpret_cast<uint4*>(sV + o) = vv;
+      *reinterpret_cast<uint4*>(sD + o) = dv;
+      float d = bf16_lo(dv.x) * bf16_lo(ov.x) + bf16_hi(dv.x) * bf16_hi(ov.x) +
+                bf16_lo(dv.y) * bf16_lo(ov.y) + bf16_hi(dv.y) * bf16_hi(ov.y) +
+                bf16_lo(dv.z) * bf16_lo(ov.z) + bf16_hi(dv.z) * bf16_hi(ov.z) +
+                bf16_lo(dv.w) * bf16_lo(ov.w) + bf16_hi(dv.w) * bf16_hi(ov.w);
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      if (c == 0) {
+        sDel[row] = d;
+        sLse[row] = ok ? lse[(long)pair * S + row] : INFINITY;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int r32 = lane & 31, h2 = lane >> 5;
+  const int tr_q = (lane >> 2) & 3;
+  const int tr_ch = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);  // + 4*db
+  const int tr_byte = (lane & 1) * 8;
+
+  // ================================ pass A: dK, dV ================================================
+  for (int ki = wave; ki < PAIRS * NKB; ki += 4) {
+    const int pi = ki / NKB, kb = ki - pi * NKB;
+    const int pair = pair0 + pi;
+    if (pair >= total_pairs || kb * 32 >= S) continue;
+    const int b = pair / H, h = pair - b * H;
+    const char* sQ = smem + pi * PAIR_BYTES;
+    const char* sK = sQ + TILE;
+    const char* sV = sK + TILE;
+    const char* sD = sV + TILE;
+    const float* sLse = reinterpret_cast<const float*>(sD + TILE);
+    const float* sDel = sLse + SP;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(sK + du_off(kb * 32 + r32, ks * 2 + h2));
+      vf[ks] = *reinterpret_cast<const bf16x8*>(sV + du_off(kb * 32 + r32, ks * 2 + h2));
+    }
+    f32x16 dVt[2], dKt[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dVt[db][r] = 0.f; dKt[db][r] = 0.f; }
+
+#pragma unroll 1
+    for (int qb = 0; qb < NKB; ++qb) {
+      if (qb * 32 >= S) break;
+      f32x16 sa, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + du_off(qb * 32 + r32, ks * 2 + h2));
+        const bf16x8 df = *reinterpret_cast<const bf16x8*>(sD + du_off(qb * 32 + r32, ks * 2 + h2));
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+      }
+      // rows of the accumulators are queries qb*32 + 8g + 4h2 + (0..3)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 l4 = *reinterpret_cast<const float4*>(sLse + qb * 32 + 8 * g + 4 * h2);
+        const float4 d4 = *reinterpret_cast<const float4*>(sDel + qb * 32 + 8 * g + 4 * h2);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+        const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float pe = exp2f(sa[r] * c_l2 - lv[e] * 1.44269504088896340736f);
+          sa[r] = pe;
+          dp[r] = pe * (dp[r] - dl[e]) * scale;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pb, dsb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pb[j] = (bf16)sa[8 * s + j]; dsb[j] = (bf16)dp[8 * s + j]; }
+        const int q0 = qb * 32 + 16 * s + 4 * h2 + tr_q;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int o_lo = du_off(q0, 4 * db + tr_ch) + tr_byte;
+          const int o_hi = du_off(q0 + 8, 4 * db + tr_ch) + tr_byte;
+          const bf16x4 dlo = tr_read(sD + o_lo), dhi = tr_read(sD + o_hi);
+          const bf16x4 qlo = tr_read(sQ + o_lo), qhi = tr_read(sQ + o_hi);
+          const bf16x8 dOt = bf16x8{dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
+          const bf16x8 Qt = bf16x8{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+          dVt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOt, pb, dVt[db], 0, 0, 0);
+          dKt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt, dsb, dKt[db], 0, 0, 0);
+        }
+      }
+    }
+    const int key = kb * 32 + r32;
+    if (key < S) {
+      bf16* krow = dqkv + ((long)b * S + key) * lddq + E + h * 64;
+      bf16* vrow = krow + E;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 w;
+          w.x = pack_bf16x2(dKt[db][4 * g + 0], dKt[db][4 * g + 1]);
+          w.y = pack_bf16x2(dKt[db][4 * g + 2], dKt[db][4 * g + 3]);
+          *reinterpret_cast<uint2*>(krow + db * 32 + 8 * g + 4 * h2) = w;
+          w.x = pack_bf16x2(dVt[db][4 * g + 0], dVt[db][4 * g + 1]);
+          w.y = pack_bf16x2(dVt[db][4 * g + 2], dVt[db][4 * g + 3]);
+          *reinterpret_cast<uint2*>(vrow + db * 32 + 8 * g + 4 * h2) = w;
+        }
+    }
+  }
+
+  // ================================ pass B: dQ =====================================================
+  for (int qi = wave; qi < PAIRS * NKB; qi += 4) {
+    const int pi = qi / NKB, qb = qi - pi * NKB;
+    const int pair = pair0 + pi;
+    if (pair >= total_pairs || qb * 32 >= S) continue;
+    const int b = pair / H, h = pair - b * H;
+    const char* sQ = smem + pi * PAIR_BYTES;
+    const char* sK = sQ + TILE;
+    const char* sV = sK + TILE;
+    const char* sD = sV + TILE;
+    const float* sLse = reinterpret_cast<const float*>(sD + TILE);
+    const float* sDel = sLse + SP;
+    bf16x8 qf[4], df[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(sQ + du_off(qb * 32 + r32, ks * 2 + h2));
+      df[ks] = *reinterpret_cast<const bf16x8*>(sD + du_off(qb * 32 + r32, ks * 2 + h2));
+    }
+    const float lse_q = sLse[qb * 32 + r32] * 1.44269504088896340736f;
+    const float del_q = sDel[qb * 32 + r32];
+    f32x16 dQt[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dQt[db][r] = 0.f;
+#pragma unroll 1
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb * 32 >= S) break;
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(sK + du_off(kb * 32 + r32, ks * 2 + h2));
+        const bf16x8 vfr = *reinterpret_cast<const bf16x8*>(sV + du_off(kb * 32 + r32, ks * 2 + h2));
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, df[ks], dpt, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        const float pe = key < S ? exp2f(st[r] * c_l2 - lse_q) : 0.f;
+        dpt[r] = pe * (dpt[r] - del_q) * scale;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 dsb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsb[j] = (bf16)dpt[8 * s + j];
+        const int k0 = kb * 32 + 16 * s + 4 * h2 + tr_q;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const bf16x4 lo = tr_read(sK + du_off(k0, 4 * db + tr_ch) + tr_byte);
+          const bf16x4 hi = tr_read(sK + du_off(k0 + 8, 4 * db + tr_ch) + tr_byte);
+          const bf16x8 Kt = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          dQt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kt, dsb, dQt[db], 0, 0, 0);
+        }
+      }
+    }
+    const int query = qb * 32 + r32;
+    if (query < S) {
+      bf16* qrow = dqkv + ((long)b * S + query) * lddq + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 w;
+          w.x = pack_bf16x2(dQt[db][4 * g + 0], dQt[db][4 * g + 1]);
+          w.y = pack_bf16x2(dQt[db][4 * g + 2], dQt[db][4 * g + 3]);
+          *reinterpret_cast<uint2*>(qrow + db * 32 + 8 * g + 4 * h2) = w;
+        }
+    }
+  }
+}
+
+template <int NKB>
+int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, bf16* dqkv, int B, int S, int H,
+                    long ldq, long ldo, long lddo, long lddq, float scale, hipStream_t st) {
+  constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
+  constexpr int LDS = PAIRS * (4 * 32 * NKB * 128 + 32 * NKB * 8);
+  static bool attr_set = false;
+  if (LDS > 65536 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      rvit_set_error("attn_bwd: cannot raise LDS limit to %d: %s", LDS, hipGetErrorString(e));
+      return RVIT_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int total = B * H;
+  const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
+  hipLaunchKernelGGL((attn_bwd_kernel<NKB>), dim3(grid), dim3(256), LDS, st, qkv, O, dO, lse, dqkv, total, S, H, ldq,
+                     ldo, lddo, lddq, scale);
+  RVIT_CHECK_LAUNCH("attn_bwd");
+  return RVIT_OK;
+}
+
 }  // namespace
 
 int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
@@ -200,5 +467,30 @@ int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int
     case 8: return launch_attn_fwd<8>(q, o, lse, B, S, H, ldq, ldo, scale, st);
   }
   rvit_set_error("attn_fwd: S=%d unsupported", S);
+  return RVIT_EUNSUPPORTED;
+}
+
+int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
+                       long ldq, long ldo, long lddo, long lddq, float scale, hipStream_t st) {
+  RVIT_CHECK_ARG(qkv && O && dO && lse && dqkv, "attn_bwd: null pointer");
+  RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_bwd: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
+  RVIT_CHECK_ARG(ldq >= 3L * H * 64 && lddq >= 3L * H * 64 && ldo >= (long)H * 64 && lddo >= (long)H * 64 &&
+                     ((ldq | lddq | ldo | lddo) & 7) == 0,
+                 "attn_bwd: bad pitches");
+  RVIT_CHECK_ARG(rvit_aligned16(qkv) && rvit_aligned16(O) && rvit_aligned16(dO) && rvit_aligned16(dqkv),
+                 "attn_bwd: alignment");
+  const bf16 *q = (const bf16*)qkv, *o = (const bf16*)O, *d = (const bf16*)dO;
+  bf16* dq = (bf16*)dqkv;
+  switch ((S + 31) / 32) {
+    case 1: return launch_attn_bwd<1>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+    case 2: return launch_attn_bwd<2>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+    case 3: return launch_attn_bwd<3>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+    case 4: return launch_attn_bwd<4>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+    case 5: return launch_attn_bwd<5>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+    case 6: return launch_attn_bwd<6>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+    case 7: return launch_attn_bwd<7>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+    case 8: return launch_attn_bwd<8>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+  }
+  rvit_set_error("attn_bwd: S=%d unsupported", S);
   return RVIT_EUNSUPPORTED;
 }

@@ -89,13 +89,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
       const int b = (int)(g / hw);
       const int rem = (int)(g - (long)b * hw);
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      const int hi0 = ok ? ho * p.stride - p.pad : -20000;
-      const int wi0 = wo * p.stride - p.pad;
-      a_pix[i] = (b * p.H + hi0) * p.W + wi0;
+      int hi0, wi0;
+      if (p.transposed) {  // rows are pixels of dX; taps walk dY at (ho + pad - kh) / stride
+        hi0 = ok ? ho + p.pad : -20000;
+        wi0 = wo + p.pad;
+        a_pix[i] = b * p.H * p.W;
+      } else {
+        hi0 = ok ? ho * p.stride - p.pad : -20000;
+        wi0 = wo * p.stride - p.pad;
+        a_pix[i] = (b * p.H + hi0) * p.W + wi0;
+      }
       a_hw[i] = (hi0 << 16) | (wi0 & 0xffff);
       a_row[i] = p.A;
     } else {
-      a_row[i] = ok ? p.A + grow * p.lda : nullptr;
+      long arow = grow;
+      if (p.a_row_group > 0) {
+        const long gq = grow / p.a_row_group;
+        arow = gq * (p.a_row_group + p.a_row_extra) + (grow - gq * p.a_row_group) + p.a_row_extra;
+      }
+      a_row[i] = ok ? p.A + arow * p.lda : nullptr;
       a_pix[i] = 0;
       a_hw[i] = 0;
     }
@@ -126,11 +138,23 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
     const bool k_ok = k_issue < p.K;                                                             \
     if constexpr (GATHER) {                                                                      \
       const int dpix = g_kh * p.W + g_kw;                                                        \
-      _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                         \
-        const int hi = (a_hw[i] >> 16) + g_kh, wi = (int)(short)(a_hw[i] & 0xffff) + g_kw;       \
-        const bool ok = k_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;    \
-        const bf16* src = ok ? p.A + (long)(a_pix[i] + dpix) * p.Cpix + g_off : zero_src;        \
-        glds16(src, dstA + i * (RPP * 128));                                                            \
+      if (p.transposed) {                                                                        \
+        const int sh = p.stride >> 1; /* stride 1 or 2 */                                        \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                       \
+          const int hn = (a_hw[i] >> 16) - g_kh, wn_ = (int)(short)(a_hw[i] & 0xffff) - g_kw;    \
+          const int hi = hn >> sh, wi = wn_ >> sh;                                               \
+          const bool ok = k_ok && hn >= 0 && wn_ >= 0 && ((hn | wn_) & (p.stride - 1)) == 0 &&   \
+                          hi < p.H && wi < p.W;                                                  \
+          const bf16* src = ok ? p.A + (long)(a_pix[i] + hi * p.W + wi) * p.Cpix + g_off : zero_src; \
+          glds16(src, dstA + i * (RPP * 128));                                                   \
+        }                                                                                        \
+      } else {                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                       \
+          const int hi = (a_hw[i] >> 16) + g_kh, wi = (int)(short)(a_hw[i] & 0xffff) + g_kw;     \
+          const bool ok = k_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;  \
+          const bf16* src = ok ? p.A + (long)(a_pix[i] + dpix) * p.Cpix + g_off : zero_src;      \
+          glds16(src, dstA + i * (RPP * 128));                                                   \
+        }                                                                                        \
       }                                                                                          \
     } else {                                                                                     \
       _Pragma("unroll") for (int i = 0; i < A_IT; ++i) {                                         \
@@ -245,6 +269,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n + 4);
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
       }
+      if (p.gate) {
+        const uint4 gq = *reinterpret_cast<const uint4*>(p.G + orow * p.ldg + n);
+        const float gv[8] = {bf16_lo(gq.x), bf16_hi(gq.x), bf16_lo(gq.y), bf16_hi(gq.y),
+                             bf16_lo(gq.z), bf16_hi(gq.z), bf16_lo(gq.w), bf16_hi(gq.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          v[e] *= p.gate == RVIT_GATE_GELU_GRAD ? gelu_erf_grad(gv[e]) : (gv[e] > 0.f ? 1.f : 0.f);
+      }
       if (p.C2) {
         uint4 o;
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
@@ -287,6 +319,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
         float x = v[e];
         if (p.scale) x *= p.scale[n + e];
         if (p.bias) x += p.bias[n + e];
+        if (p.gate) {
+          const float gv = (float)p.G[orow * p.ldg + n + e];
+          x *= p.gate == RVIT_GATE_GELU_GRAD ? gelu_erf_grad(gv) : (gv > 0.f ? 1.f : 0.f);
+        }
         if (p.C2) p.C2[orow * p.ldc2 + n + e] = (bf16)x;
         if (p.R) x += p.r_f32 ? ((const float*)p.R)[rrow * p.ldr + n + e]
                               : (float)((const bf16*)p.R)[rrow * p.ldr + n + e];
@@ -342,6 +378,10 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     RVIT_CHECK_ARG((a.Cpix & 3) == 0 && (a.seg_len & 7) == 0 && a.seg_len > 0 && a.KW > 0,
                    "conv: bad gather geometry Cpix=%d seg_len=%d KW=%d", a.Cpix, a.seg_len, a.KW);
     RVIT_CHECK_ARG(a.H < 20000 && a.W < 20000, "conv: image too large for packed coordinates");
+    RVIT_CHECK_ARG(!a.transposed || a.stride == 1 || a.stride == 2, "conv dgrad: stride must be 1 or 2");
+  }
+  if (a.gate) {
+    RVIT_CHECK_ARG(a.G && a.ldg >= a.N, "gemm: gate operand missing");
   }
   if (a.M == 0) return RVIT_OK;
   const int forced = a.tile;

@@ -14,6 +14,9 @@ struct GemmArgs {
   // gather (implicit-GEMM conv) geometry; mode 0 = plain row-major A
   int mode;
   int H, W, Cpix, Ho, Wo, KW, stride, pad, seg_len;
+  int transposed;    // gather: 1 = transposed conv (input-gradient of a strided conv)
+  int a_row_group;   // plain: >0 remaps the A row like row_group/row_extra below
+  int a_row_extra;
   // epilogue
   void* C;
   long ldc;
@@ -22,6 +25,9 @@ struct GemmArgs {
   long ldc2;
   const float* scale;  // per-column multiplier (folded BatchNorm), may be null
   const float* bias;   // per-column addend, may be null
+  const bf16* G;       // gate operand (same rows as C): gelu'(G) or (G > 0) multiplies the value
+  long ldg;
+  int gate;
   const void* R;       // residual, added before the activation, may be null
   long ldr;
   int r_f32;
@@ -35,12 +41,41 @@ struct GemmArgs {
 
 int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream);
 
+// Argument block of the weight-gradient kernel (wgrad.hip): dW[N,K] += dY^T X.
+struct WgradArgs {
+  const bf16* dY;  // [M, ldy]
+  long ldy;
+  int y_row_group, y_row_extra;  // optional row remap of dY (token rows past the cls row)
+  const bf16* X;   // plain: [M, ldx]; gather: NHWC activation
+  long ldx;
+  int x_row_group, x_row_extra;
+  float* dW;       // [N_store, ldw] fp32, accumulated with atomics
+  long ldw;
+  long M;
+  int N, N_store, K;
+  int mode;        // 0 plain, 1 gather
+  int H, W, Cpix, Ho, Wo, KW, stride, pad, seg_len;
+  int splits;      // 0 = auto
+};
+
+int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st);
+
 int rvit_layernorm_fwd_impl(const void* x, int x_f32, long ldx, const float* gamma, const float* beta, void* y,
                             int y_f32, long ldy, float* mean, float* rstd, long rows, int E, float eps,
                             hipStream_t st);
+int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
+                            const float* gamma, float* dxs, long lddx, int accumulate, void* dx_bf16, long lddb,
+                            float* dgamma, float* dbeta, long rows, int E, hipStream_t st);
 int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
                        hipStream_t st);
+int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
+                       long ldq, long ldo, long lddo, long lddq, float scale, hipStream_t st);
 int rvit_input_pack_impl(const float* x, void* out, int B, int C, int H, int W, int Hp, int Wp, int pt, int pl,
                          hipStream_t st);
 int rvit_maxpool_impl(const void* x, void* y, void* argmax, int B, int H, int W, int C, hipStream_t st);
 int rvit_embed_cls_impl(const float* cls, const float* pos, float* x, int B, int S, int E, hipStream_t st);
+int rvit_ce_loss_impl(const float* logits, long ldl, const long* labels, float* loss_sum, float* dlogits, long lddl,
+                      void* dlogits_bf16, long lddb, int B, int C, int C_pad, float eps, float gscale, hipStream_t st);
+int rvit_colsum_impl(const void* a, long lda, float* out, long M, int N, long row_group, long row_extra,
+                     hipStream_t st);
+int rvit_batch_sum_impl(const float* x, long ldb, float* out, int B, long n, hipStream_t st);

@@ -1,0 +1,239 @@
+// Weight-gradient GEMM ("TN"): dW[N,K] += sum_m dY[m,n] * X[m,k], bf16 operands, fp32 atomics.
+//
+// Backward of every nn.Linear / conv weight on the path (autograd of train_vit.py:141-171 run by
+// `scaler.scale(loss).backward()`, train_vit.py:939).  The contraction runs over the ROW index of
+// both row-major operands, so fragments are columns of the staged tiles: they are produced by the
+// gfx950 transposing LDS read (ds_read_b64_tr_b16), no transposed copies of activations exist in
+// HBM.  X may be gathered implicit-GEMM style from an NHWC activation (conv weight gradients).
+//
+// Structure: 256 threads, 128(n) x 128(k) output tile, 64-row M tiles DMA'd global->LDS
+// (global_load_lds_dwordx4) into a 2-stage ring; 256-byte LDS rows whose 32-byte segments are
+// XOR-swizzled (on the DMA source address and on the read) so that every transposing read is
+// bank-conflict free; the M range is split over gridDim.y and partial tiles are added with
+// global_atomic_add_f32 after restaging through LDS (256 contiguous bytes per wave instruction,
+// the full-rate atomic shape).  Accumulating into dW matches autograd's `.grad +=` semantics.
+#include "common.h"
+#include "rvit_internal.h"
+
+namespace {
+
+__device__ uint4 g_zero_page_w[4];
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  return __builtin_bit_cast(bf16x4, r);
+}
+// exact floor division for 0 <= m < 2^31, 0 < d < 2^15 via float reciprocal + one fix-up
+__device__ __forceinline__ int fdiv(int m, int d, float inv_d) {
+  int q = (int)((float)m * inv_d);
+  int r = m - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; }
+  return q;
+}
+
+constexpr int TM = 64;             // M rows per staged tile
+constexpr int TILE_B = TM * 256;   // bytes of one operand tile (64 rows x 128 bf16)
+
+template <bool GATHER>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (dY tile + X tile)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave >> 1, wk = wave & 1;  // wave's 64x64 quadrant of the 128x128 output tile
+
+  const int ntk = (p.K + 127) / 128;
+  const int tile_n = blockIdx.x / ntk, tile_k = blockIdx.x - tile_n * ntk;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+
+  // M range of this split, in 64-row tiles
+  const long mtiles = (p.M + TM - 1) / TM;
+  const long per = (mtiles + gridDim.y - 1) / gridDim.y;
+  const long mt_begin = (long)blockIdx.y * per;
+  long mt_end = mt_begin + per;
+  if (mt_end > mtiles) mt_end = mtiles;
+  const int nmt = (int)(mt_end - mt_begin);
+  if (nmt <= 0) return;
+
+  // DMA geometry: thread -> (row within a 16-row pass, destination chunk slot); source chunk is
+  // the slot XOR the row swizzle
+  const int lrow = t >> 4;
+  const int f_w = (lrow & 3) | (((lrow >> 3) & 1) << 2);
+  const int lc = (t & 15) ^ (f_w << 1);
+  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_page_w);
+  const int ncol = n0 + lc * 8;  // this thread's dY column chunk
+  const int kcol = k0 + lc * 8;  // this thread's X column chunk
+  const bool n_ok = ncol < p.N;
+  const bool k_ok = kcol < p.K;
+  int g_kh = 0, g_kw = 0, g_off = 0;
+  float inv_hw = 0.f, inv_wo = 0.f;
+  if constexpr (GATHER) {
+    const int seg = kcol / p.seg_len;
+    g_off = kcol - seg * p.seg_len;
+    g_kh = seg / p.KW;
+    g_kw = seg - g_kh * p.KW;
+    inv_hw = 1.0f / (float)(p.Ho * p.Wo);
+    inv_wo = 1.0f / (float)p.Wo;
+  }
+  char* const wave_dst = smem + wave * 1024;
+
+#define ISSUE_MT(stage, mt)                                                                    \
+  do {                                                                                         \
+    char* dY_dst = wave_dst + (stage) * (2 * TILE_B);                                          \
+    char* dX_dst = dY_dst + TILE_B;                                                            \
+    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                         \
+      const long m = (mt) * TM + ps * 16 + lrow;                                               \
+      const bool m_ok = m < p.M && (mt) < mt_end;                                              \
+      long yr = m;                                                                             \
+      if (p.y_row_group > 0) {                                                                 \
+        const long gy = m / p.y_row_group;                                                     \
+        yr = gy * (p.y_row_group + p.y_row_extra) + (m - gy * p.y_row_group) + p.y_row_extra;  \
+      }                                                                                        \
+      const bf16* ysrc = (m_ok && n_ok) ? p.dY + yr * p.ldy + ncol : zero_src;                 \
+      glds16(ysrc, dY_dst + ps * 4096);                                                        \
+      const bf16* xsrc = zero_src;                                                             \
+      if constexpr (GATHER) {                                                                  \
+        if (m_ok && k_ok) {                                                                    \
+          const int mi = (int)m;                                                               \
+          const int b = fdiv(mi, p.Ho * p.Wo, inv_hw);                                         \
+          const int rem = mi - b * p.Ho * p.Wo;                                                \
+          const int ho = fdiv(rem, p.Wo, inv_wo);                                              \
+          const int wo = rem - ho * p.Wo;                                                      \
+          const int hi = ho * p.stride - p.pad + g_kh, wi = wo * p.stride - p.pad + g_kw;      \
+          if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)                    \
+            xsrc = p.X + ((long)(b * p.H + hi) * p.W + wi) * p.Cpix + g_off;                   \
+        }                                                                                      \
+      } else {                                                                                 \
+        if (m_ok && k_ok) {                                                                    \
+          long xr = m;                                                                         \
+          if (p.x_row_group > 0) {                                                             \
+            const long g = m / p.x_row_group;                                                  \
+            xr = g * (p.x_row_group + p.x_row_extra) + (m - g * p.x_row_group) + p.x_row_extra; \
+          }                                                                                    \
+          xsrc = p.X + xr * p.ldx + kcol;                                                      \
+        }                                                                                      \
+      }                                                                                        \
+      glds16(xsrc, dX_dst + ps * 4096);                                                        \
+    }                                                                                          \
+  } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposing-read geometry of this lane
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int f_r = q | ((g & 1) << 2);
+  const int rd_row = 8 * g + q;                                   // + ks*32 (+4 for the 2nd read)
+  const int rd_chunk_lo = pp >> 1;                                // + column-block chunk base
+  const int rd_byte = (pp & 1) * 8;
+
+  ISSUE_MT(0, mt_begin);
+  int stage = 0;
+  for (int it = 0; it < nmt; ++it) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    ISSUE_MT(stage ^ 1, mt_begin + it + 1);  // past mt_end: zero pages (keeps the protocol uniform)
+    const char* sY = smem + stage * (2 * TILE_B);
+    const char* sX = sY + TILE_B;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 yf[4], xf[4];
+      const int rbase = (ks * 32 + rd_row) * 256 + rd_byte;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = ((wn * 8 + i * 2 + rd_chunk_lo) ^ (f_r << 1)) << 4;
+        const bf16x4 lo = tr_read(sY + rbase + ch);
+        const bf16x4 hi = tr_read(sY + rbase + 4 * 256 + ch);
+        yf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = ((wk * 8 + j * 2 + rd_chunk_lo) ^ (f_r << 1)) << 4;
+        const bf16x4 lo = tr_read(sX + rbase + ch);
+        const bf16x4 hi = tr_read(sX + rbase + 4 * 256 + ch);
+        xf[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    stage ^= 1;
+  }
+  wait_vmcnt<0>();
+#undef ISSUE_MT
+  __builtin_amdgcn_s_barrier();
+
+  // ---- restage through LDS and add whole 256-byte rows atomically ---------------------------------
+  // lane holds D[row n = 16i + 4g + r][col k = 16j + (lane&15)]
+  constexpr int EP = 64 * 4 + 16;  // fp32 row pitch of the wave-private staging area (32 rows)
+  char* ep = smem + wave * (32 * EP);
+  const int fr = lane & 15;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<float*>(ep + (ii * 16 + 4 * g + r) * EP + (j * 16 + fr) * 4) = acc[half * 2 + ii][j][r];
+    __syncthreads();
+    const int k = k0 + wk * 64 + lane;
+#pragma unroll 4
+    for (int row = 0; row < 32; ++row) {
+      const int n = n0 + wn * 64 + half * 32 + row;
+      if (n < p.N_store && k < p.K) {
+        const float v = *reinterpret_cast<const float*>(ep + row * EP + lane * 4);
+        atomicAdd(p.dW + (long)n * p.ldw + k, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
+  RVIT_CHECK_ARG(a.dY && a.X && a.dW, "wgrad: null pointer");
+  RVIT_CHECK_ARG(a.M >= 0 && a.N > 0 && a.K > 0 && a.N_store > 0 && a.N_store <= a.N, "wgrad: bad shape");
+  RVIT_CHECK_ARG((a.N & 7) == 0 && (a.K & 7) == 0 && (a.ldy & 7) == 0 && a.ldy >= a.N && a.ldw >= a.K,
+                 "wgrad: N, K, ldy must be multiples of 8 (N=%d K=%d ldy=%ld)", a.N, a.K, a.ldy);
+  RVIT_CHECK_ARG(rvit_aligned16(a.dY) && rvit_aligned16(a.X), "wgrad: operands must be 16-byte aligned");
+  if (a.mode == 0) {
+    RVIT_CHECK_ARG((a.ldx & 7) == 0 && a.ldx >= a.K, "wgrad: bad ldx");
+  } else {
+    RVIT_CHECK_ARG((a.Cpix & 3) == 0 && (a.seg_len & 7) == 0 && a.seg_len > 0 && a.KW > 0 && a.Ho > 0 && a.Wo > 0,
+                   "wgrad: bad gather geometry");
+    RVIT_CHECK_ARG(a.M < 0x7fffffffL && a.Ho * a.Wo < 32768 * 4 && a.Wo < 32768, "wgrad: gather index range");
+  }
+  if (a.M == 0) return RVIT_OK;
+  const long tiles = (long)((a.N + 127) / 128) * ((a.K + 127) / 128);
+  const long mtiles = (a.M + TM - 1) / TM;
+  long splits = a.splits > 0 ? a.splits : (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU
+  if (splits > mtiles) splits = mtiles;
+  if (splits > 65535) splits = 65535;
+  if (splits < 1) splits = 1;
+  const size_t lds = 2 * 2 * TILE_B;  // 64 KB
+  dim3 grid((unsigned)tiles, (unsigned)splits);
+  if (a.mode == 1)
+    hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL(wgrad_bf16_kernel<false>, grid, dim3(256), lds, st, a);
+  RVIT_CHECK_LAUNCH("wgrad_bf16");
+  return RVIT_OK;
+}

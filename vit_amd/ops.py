@@ -11,10 +11,12 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, RVIT_BF16, RVIT_F32, check  # noqa: F401
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, GATE_GELU_GRAD, GATE_RELU_MASK, RVIT_BF16, RVIT_F32,  # noqa: F401
+                   check)
 
 _ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
-
+_GATE = {None: 0, "gelu_grad": GATE_GELU_GRAD, "relu_mask": GATE_RELU_MASK}
+BF16 = torch.bfloat16
 
 # ---- optional per-launch profiling (bench.py) ----------------------------------------------------
 # When a list is installed with set_profiler(), every wrapper brackets its launch with HIP events on
@@ -81,24 +83,37 @@ def _rows2d(t: torch.Tensor, what: str):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
+def _vec_f32(v, n, what):
+    if v is not None and (v.dtype != torch.float32 or v.numel() != n or not v.is_contiguous()):
+        raise ValueError(f"{what} must be contiguous float32 [{n}]")
+
+
+# =================================================================================================
+# forward kernels
+# =================================================================================================
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, residual_period: int = 0,
          act: Optional[str] = None, preact: Optional[torch.Tensor] = None, row_group: int = 0, row_extra: int = 0,
-         tile: int = 0) -> torch.Tensor:
-    """out = act(scale * (a @ w.T) + bias + residual); a [M,K] bf16, w [N,K] bf16."""
-    _need_cuda(a, w, out, bias, scale, residual, preact)
-    M, K, lda = _rows2d(a, "gemm a")
+         gate: Optional[torch.Tensor] = None, gate_mode: Optional[str] = None, a_rows: Optional[int] = None,
+         a_row_group: int = 0, a_row_extra: int = 0, tile: int = 0) -> torch.Tensor:
+    """out = act(gate(scale * (a @ w.T) + bias) + residual); a [M,K] bf16, w [N,K] bf16.
+
+    a_rows/a_row_group/a_row_extra: use `a_rows` logical rows of `a` through the row remap."""
+    _need_cuda(a, w, out, bias, scale, residual, preact, gate)
+    Ma, K, lda = _rows2d(a, "gemm a")
+    M = Ma if a_rows is None else a_rows
+    if a_row_group and (M // a_row_group) * (a_row_group + a_row_extra) > Ma:
+        raise ValueError("gemm: remapped A rows exceed the tensor")
     N, K2, ldb = _rows2d(w, "gemm w")
     if K != K2:
         raise ValueError(f"gemm: K mismatch {K} vs {K2}")
-    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16:
+    if a.dtype != BF16 or w.dtype != BF16:
         raise TypeError("gemm: a and w must be bfloat16")
     mo, no, ldc = _rows2d(out, "gemm out")
     rows_out = M if row_group == 0 else (M // row_group) * (row_group + row_extra)
     if no != N or mo < rows_out:
         raise ValueError(f"gemm: out shape {tuple(out.shape)} incompatible with M={M} N={N}")
-    ldr = 0
-    r_dt = RVIT_F32
+    ldr, r_dt = 0, RVIT_F32
     if residual is not None:
         rr, rn, ldr = _rows2d(residual, "gemm residual")
         if rn != N or rr < (residual_period if residual_period else rows_out):
@@ -107,18 +122,23 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
     ldp = 0
     if preact is not None:
         pr, pn, ldp = _rows2d(preact, "gemm preact")
-        if pn != N or pr < rows_out or preact.dtype != torch.bfloat16:
+        if pn != N or pr < rows_out or preact.dtype != BF16:
             raise ValueError("gemm: preact must be bf16 [rows, N]")
-    for v, nm in ((bias, "bias"), (scale, "scale")):
-        if v is not None and (v.dtype != torch.float32 or v.numel() != N or not v.is_contiguous()):
-            raise ValueError(f"gemm: {nm} must be contiguous float32 [N]")
+    ldg = 0
+    if gate is not None:
+        gr, gn, ldg = _rows2d(gate, "gemm gate")
+        if gn != N or gr < rows_out or gate.dtype != BF16 or gate_mode not in ("gelu_grad", "relu_mask"):
+            raise ValueError("gemm: gate must be bf16 [rows, N] with gate_mode gelu_grad|relu_mask")
+    _vec_f32(bias, N, "gemm: bias")
+    _vec_f32(scale, N, "gemm: scale")
     lib = _lib.load()
     nb = (M * K + N * K) * 2 + M * N * out.element_size() + (M * N * residual.element_size() if residual is not None
                                                              and not residual_period else 0)
     with _Span("gemm_bf16", 2 * M * N * K, nb):
-        check(lib.rvit_gemm_bf16(a.data_ptr(), lda, w.data_ptr(), ldb, out.data_ptr(), ldc, _dt(out), M, N, K,
-                                 _ptr(scale), _ptr(bias), _ptr(residual), ldr, r_dt, residual_period, _ACT[act],
-                                 _ptr(preact), ldp, row_group, row_extra, tile, _stream()), "rvit_gemm_bf16")
+        check(lib.rvit_gemm_bf16(a.data_ptr(), lda, a_row_group, a_row_extra, w.data_ptr(), ldb, out.data_ptr(), ldc,
+                                 _dt(out), M, N, K, _ptr(scale), _ptr(bias), _ptr(gate), ldg, _GATE[gate_mode],
+                                 _ptr(residual), ldr, r_dt, residual_period, _ACT[act], _ptr(preact), ldp, row_group,
+                                 row_extra, tile, _stream()), "rvit_gemm_bf16")
     return out
 
 
@@ -130,19 +150,17 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
     _need_cuda(x, w, out, scale, bias, residual)
     if x.dim() != 4 or out.dim() != 4 or not x.is_contiguous() or not out.is_contiguous() or not w.is_contiguous():
         raise ValueError("conv2d: x/out must be contiguous NHWC 4-D tensors, w contiguous")
-    if x.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+    if x.dtype != BF16 or w.dtype != BF16 or out.dtype != BF16:
         raise TypeError("conv2d: bf16 only")
     B, H, W, Cpix = x.shape
     Bo, Ho, Wo, Cout = out.shape
     seg = Cpix if seg_len is None else seg_len
     if Bo != B or w.shape != (Cout, kh * kw * seg):
         raise ValueError(f"conv2d: weight shape {tuple(w.shape)} != {(Cout, kh * kw * seg)} or batch mismatch")
-    if residual is not None and (residual.shape != out.shape or residual.dtype != torch.bfloat16
-                                 or not residual.is_contiguous()):
+    if residual is not None and (residual.shape != out.shape or residual.dtype != BF16 or not residual.is_contiguous()):
         raise ValueError("conv2d: residual must match out (bf16, contiguous)")
-    for v, nm in ((bias, "bias"), (scale, "scale")):
-        if v is not None and (v.dtype != torch.float32 or v.numel() != Cout or not v.is_contiguous()):
-            raise ValueError(f"conv2d: {nm} must be contiguous float32 [Cout]")
+    _vec_f32(bias, Cout, "conv2d: bias")
+    _vec_f32(scale, Cout, "conv2d: scale")
     lib = _lib.load()
     # algorithmic work: true taps only (the 7x7 stem conv's zero taps / 4th channel are padding)
     true_k = kh * kw * seg if seg_len is None else kh * (kw * seg - seg // 8 - (seg - seg // 8) // 4)
@@ -162,13 +180,12 @@ def conv2d_tokens(x: torch.Tensor, w: torch.Tensor, tokens: torch.Tensor, pos_em
     Bt, S, E = tokens.shape
     if Bt != B or S != ho * wo + 1 or tokens.dtype != torch.float32 or not tokens.is_contiguous():
         raise ValueError("conv2d_tokens: tokens must be contiguous float32 [B, ho*wo+1, E]")
-    if w.shape != (E, kh * kw * seg_len) or w.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 \
-            or not w.is_contiguous() or not x.is_contiguous():
+    if w.shape != (E, kh * kw * seg_len) or w.dtype != BF16 or x.dtype != BF16 or not w.is_contiguous() \
+            or not x.is_contiguous():
         raise ValueError("conv2d_tokens: bad x / w")
     if pos_embed.dtype != torch.float32 or pos_embed.numel() != S * E or not pos_embed.is_contiguous():
         raise ValueError("conv2d_tokens: pos_embed must be contiguous float32 [S,E]")
-    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != E or not bias.is_contiguous()):
-        raise ValueError("conv2d_tokens: bias must be contiguous float32 [E]")
+    _vec_f32(bias, E, "conv2d_tokens: bias")
     true_k = kh * (seg_len // 4) * 3  # px4 runs carry 3 real channels
     with _Span("conv2d_tokens", 2 * B * ho * wo * E * true_k, _nbytes(x, w, tokens)):
         check(_lib.load().rvit_conv2d_tokens_fwd(x.data_ptr(), w.data_ptr(), tokens.data_ptr(), B, H, W, Cpix,
@@ -182,7 +199,7 @@ def input_pack(x: torch.Tensor, out: torch.Tensor, pad_top: int, pad_left: int) 
     _need_cuda(x, out)
     if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4:
         raise ValueError("input_pack: x must be contiguous float32 NCHW")
-    if out.dtype != torch.bfloat16 or not out.is_contiguous() or out.dim() != 4 or out.shape[3] != 4:
+    if out.dtype != BF16 or not out.is_contiguous() or out.dim() != 4 or out.shape[3] != 4:
         raise ValueError("input_pack: out must be contiguous bf16 [B,Hp,Wp,4]")
     B, C, H, W = x.shape
     if out.shape[0] != B:
@@ -197,7 +214,7 @@ def maxpool3x3s2(x: torch.Tensor, out: torch.Tensor, argmax: Optional[torch.Tens
     _need_cuda(x, out, argmax)
     B, H, W, C = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    if tuple(out.shape) != (B, Ho, Wo, C) or x.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+    if tuple(out.shape) != (B, Ho, Wo, C) or x.dtype != BF16 or out.dtype != BF16:
         raise ValueError(f"maxpool: out must be bf16 {(B, Ho, Wo, C)}")
     if not x.is_contiguous() or not out.is_contiguous():
         raise ValueError("maxpool: contiguous NHWC required")
@@ -230,13 +247,12 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
     _need_cuda(x, gamma, beta, out, mean, rstd)
     rows, E, ldx = _rows2d(x, "layernorm x")
     ro, Eo, ldy = _rows2d(out, "layernorm out")
-    if ro != rows or Eo != E or gamma.numel() != E or beta.numel() != E:
+    if ro != rows or Eo != E:
         raise ValueError("layernorm: shape mismatch")
-    if gamma.dtype != torch.float32 or beta.dtype != torch.float32:
-        raise TypeError("layernorm: gamma/beta must be float32")
-    for s in (mean, rstd):
-        if s is not None and (s.dtype != torch.float32 or s.numel() != rows or not s.is_contiguous()):
-            raise ValueError("layernorm: mean/rstd must be contiguous float32 [rows]")
+    _vec_f32(gamma, E, "layernorm: gamma")
+    _vec_f32(beta, E, "layernorm: beta")
+    _vec_f32(mean, rows, "layernorm: mean")
+    _vec_f32(rstd, rows, "layernorm: rstd")
     with _Span("layernorm_fwd", 0, rows * E * (x.element_size() + out.element_size()) + 8 * E):
         check(_lib.load().rvit_layernorm_fwd(x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(),
                                              out.data_ptr(), _dt(out), ldy, _ptr(mean), _ptr(rstd), rows, E, eps,
@@ -252,12 +268,165 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, lse:
     To, Wo, ldo = _rows2d(out, "attention out")
     if T != B * S or To != T or W3 != 3 * H * 64 or Wo != H * 64:
         raise ValueError(f"attention: shapes {tuple(qkv.shape)} / {tuple(out.shape)} do not match B={B} S={S} H={H}")
-    if qkv.dtype != torch.bfloat16 or out.dtype != torch.bfloat16:
+    if qkv.dtype != BF16 or out.dtype != BF16:
         raise TypeError("attention: bf16 only")
-    if lse is not None and (lse.dtype != torch.float32 or lse.numel() != B * H * S or not lse.is_contiguous()):
-        raise ValueError("attention: lse must be contiguous float32 [B,H,S]")
+    _vec_f32(lse, B * H * S, "attention: lse")
     sc = (1.0 / 8.0) if scale is None else float(scale)
     with _Span("attn_fwd", 4 * B * H * S * S * 64, _nbytes(qkv, out, lse)):
         check(_lib.load().rvit_attn_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, S, H, ldq, ldo, sc, _stream()),
               "rvit_attn_fwd")
+    return out
+
+
+# =================================================================================================
+# backward / loss kernels
+# =================================================================================================
+def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, rows: Optional[int] = None, n_store: Optional[int] = None,
+          y_row_group: int = 0, y_row_extra: int = 0, x_row_group: int = 0, x_row_extra: int = 0,
+          splits: int = 0) -> torch.Tensor:
+    """dw[N_store,K] += dy[M,N].T @ x[M,K]  (bf16 operands, fp32 atomics)."""
+    _need_cuda(dy, x, dw)
+    My, N, ldy = _rows2d(dy, "wgrad dy")
+    Mx, K, ldx = _rows2d(x, "wgrad x")
+    M = rows if rows is not None else min(My, Mx)
+    ns, Kw, ldw = _rows2d(dw, "wgrad dw")
+    n_store = ns if n_store is None else n_store
+    if dy.dtype != BF16 or x.dtype != BF16 or dw.dtype != torch.float32 or Kw != K or n_store > N or n_store > ns:
+        raise ValueError(f"wgrad: bad operands dy{tuple(dy.shape)} x{tuple(x.shape)} dw{tuple(dw.shape)}")
+    with _Span("wgrad_bf16", 2 * M * N * K, (M * N + M * K) * 2 + n_store * K * 4):
+        check(_lib.load().rvit_wgrad_bf16(dy.data_ptr(), ldy, y_row_group, y_row_extra, x.data_ptr(), ldx, x_row_group,
+                                          x_row_extra, dw.data_ptr(), ldw, M, N, n_store, K, splits, _stream()),
+              "rvit_wgrad_bf16")
+    return dw
+
+
+def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
+                 seg_len: Optional[int] = None, splits: int = 0) -> torch.Tensor:
+    """dw[Cout, kh*kw*seg] += dy^T gather(x); dy bf16 [B,Ho,Wo,Cout], x bf16 [B,H,W,Cpix], dw fp32."""
+    _need_cuda(dy, x, dw)
+    B, H, W, Cpix = x.shape
+    Bo, Ho, Wo, Cout = dy.shape
+    seg = Cpix if seg_len is None else seg_len
+    if Bo != B or dw.shape != (Cout, kh * kw * seg) or dw.dtype != torch.float32 or dy.dtype != BF16 or x.dtype != BF16 \
+            or not (dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()):
+        raise ValueError("conv2d_wgrad: bad operands")
+    with _Span("conv2d_wgrad", 2 * B * Ho * Wo * Cout * kh * kw * seg, _nbytes(dy, x, dw)):
+        check(_lib.load().rvit_conv2d_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cpix, seg, kh, kw,
+                                                 stride, pad, Ho, Wo, Cout, splits, _stream()),
+              "rvit_conv2d_wgrad_bf16")
+    return dw
+
+
+def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
+                 residual: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+    """dx = conv_transpose(dy, w) (+ residual); dy bf16 [B,Hy,Wy,Cout], w_t bf16 [Cin, kh*kw*Cout]."""
+    _need_cuda(dy, w_t, dx, residual)
+    B, Hy, Wy, Cout = dy.shape
+    Bx, Hx, Wx, Cin = dx.shape
+    if Bx != B or w_t.shape != (Cin, kh * kw * Cout) or dy.dtype != BF16 or dx.dtype != BF16 or w_t.dtype != BF16 \
+            or not (dy.is_contiguous() and dx.is_contiguous() and w_t.is_contiguous()):
+        raise ValueError("conv2d_dgrad: bad operands")
+    if residual is not None and (residual.shape != dx.shape or residual.dtype != BF16 or not residual.is_contiguous()):
+        raise ValueError("conv2d_dgrad: residual must match dx")
+    with _Span("conv2d_dgrad", 2 * B * Hy * Wy * Cout * kh * kw * Cin, _nbytes(dy, w_t, dx, residual)):
+        check(_lib.load().rvit_conv2d_dgrad_bf16(dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), B, Hy, Wy, Cout, kh, kw,
+                                                 stride, pad, Hx, Wx, Cin, _ptr(residual), tile, _stream()),
+              "rvit_conv2d_dgrad_bf16")
+    return dx
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
+                  dx: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, *, accumulate: bool,
+                  dx_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx (+)= LN'(dy); dgamma/dbeta += ...; optional bf16 copy of the updated dx."""
+    _need_cuda(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dx_bf16)
+    rows, E, lddy = _rows2d(dy, "layernorm_bwd dy")
+    rx, Ex, ldx = _rows2d(x, "layernorm_bwd x")
+    rd, Ed, lddx = _rows2d(dx, "layernorm_bwd dx")
+    if (rx, Ex) != (rows, E) or (rd, Ed) != (rows, E) or dy.dtype != BF16 or x.dtype != torch.float32 \
+            or dx.dtype != torch.float32:
+        raise ValueError("layernorm_bwd: shape/dtype mismatch")
+    lddb = 0
+    if dx_bf16 is not None:
+        rb, Eb, lddb = _rows2d(dx_bf16, "layernorm_bwd dx_bf16")
+        if (rb, Eb) != (rows, E) or dx_bf16.dtype != BF16:
+            raise ValueError("layernorm_bwd: dx_bf16 mismatch")
+    for v, n in ((mean, rows), (rstd, rows), (gamma, E), (dgamma, E), (dbeta, E)):
+        _vec_f32(v, n, "layernorm_bwd: vector")
+    with _Span("layernorm_bwd", 0, rows * E * (2 + 4 + 8 + (2 if dx_bf16 is not None else 0))):
+        check(_lib.load().rvit_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, mean.data_ptr(), rstd.data_ptr(),
+                                             gamma.data_ptr(), dx.data_ptr(), lddx, int(accumulate), _ptr(dx_bf16),
+                                             lddb, dgamma.data_ptr(), dbeta.data_ptr(), rows, E, _stream()),
+              "rvit_layernorm_bwd")
+    return dx
+
+
+def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, dqkv: torch.Tensor,
+                  B: int, S: int, H: int, scale: Optional[float] = None) -> torch.Tensor:
+    _need_cuda(qkv, out, dout, lse, dqkv)
+    T, W3, ldq = _rows2d(qkv, "attention_bwd qkv")
+    _, Wo, ldo = _rows2d(out, "attention_bwd out")
+    _, Wd, lddo = _rows2d(dout, "attention_bwd dout")
+    Tq, Wq, lddq = _rows2d(dqkv, "attention_bwd dqkv")
+    if T != B * S or Tq != T or W3 != 3 * H * 64 or Wq != W3 or Wo != H * 64 or Wd != Wo \
+            or any(t.dtype != BF16 for t in (qkv, out, dout, dqkv)):
+        raise ValueError("attention_bwd: shape/dtype mismatch")
+    _vec_f32(lse, B * H * S, "attention_bwd: lse")
+    sc = (1.0 / 8.0) if scale is None else float(scale)
+    with _Span("attn_bwd", 10 * B * H * S * S * 64, _nbytes(qkv, out, dout, dqkv)):
+        check(_lib.load().rvit_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                        dqkv.data_ptr(), B, S, H, ldq, ldo, lddo, lddq, sc, _stream()), "rvit_attn_bwd")
+    return dqkv
+
+
+def ce_loss(logits: torch.Tensor, labels: torch.Tensor, loss_sum: Optional[torch.Tensor],
+            dlogits: Optional[torch.Tensor], dlogits_bf16: Optional[torch.Tensor], label_smoothing: float,
+            grad_scale: float = 1.0) -> None:
+    """*loss_sum += mean smoothed CE; dlogits (f32 [B,C]) / dlogits_bf16 (bf16 [B,C_pad], zero padded)."""
+    _need_cuda(logits, labels, loss_sum, dlogits, dlogits_bf16)
+    B, C, ldl = _rows2d(logits, "ce_loss logits")
+    if logits.dtype != torch.float32 or labels.dtype != torch.int64 or labels.numel() != B or not labels.is_contiguous():
+        raise ValueError("ce_loss: logits float32 [B,C], labels int64 [B]")
+    lddl = lddb = 0
+    c_pad = C
+    if dlogits is not None:
+        _, cd, lddl = _rows2d(dlogits, "ce_loss dlogits")
+        if cd != C or dlogits.dtype != torch.float32:
+            raise ValueError("ce_loss: dlogits mismatch")
+    if dlogits_bf16 is not None:
+        _, c_pad, lddb = _rows2d(dlogits_bf16, "ce_loss dlogits_bf16")
+        if c_pad < C or dlogits_bf16.dtype != BF16:
+            raise ValueError("ce_loss: dlogits_bf16 mismatch")
+    if loss_sum is not None and (loss_sum.dtype != torch.float32 or loss_sum.numel() != 1):
+        raise ValueError("ce_loss: loss_sum must be a float32 scalar tensor")
+    with _Span("ce_loss", 0, B * C * 8):
+        check(_lib.load().rvit_ce_loss(logits.data_ptr(), ldl, labels.data_ptr(), _ptr(loss_sum), _ptr(dlogits), lddl,
+                                       _ptr(dlogits_bf16), lddb, B, C, c_pad, float(label_smoothing),
+                                       float(grad_scale), _stream()), "rvit_ce_loss")
+
+
+def colsum(a: torch.Tensor, out: torch.Tensor, *, rows: Optional[int] = None, row_group: int = 0,
+           row_extra: int = 0) -> torch.Tensor:
+    """out[n] += sum_m a[m,n]; a bf16."""
+    _need_cuda(a, out)
+    Ma, N, lda = _rows2d(a, "colsum a")
+    M = Ma if rows is None else rows
+    if a.dtype != BF16:
+        raise TypeError("colsum: a must be bf16")
+    _vec_f32(out, N, "colsum: out")
+    with _Span("colsum", 0, M * N * 2):
+        check(_lib.load().rvit_colsum_bf16(a.data_ptr(), lda, out.data_ptr(), M, N, row_group, row_extra, _stream()),
+              "rvit_colsum_bf16")
+    return out
+
+
+def batch_sum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[j] += sum_b x[b, j]; x fp32 [B, n] (row stride free), out fp32 [n]."""
+    _need_cuda(x, out)
+    B, n, ldb = _rows2d(x, "batch_sum x")
+    if x.dtype != torch.float32:
+        raise TypeError("batch_sum: float32 only")
+    _vec_f32(out.reshape(-1), n, "batch_sum: out")
+    with _Span("batch_sum", 0, B * n * 4):
+        check(_lib.load().rvit_batch_sum_f32(x.data_ptr(), ldb, out.data_ptr(), B, n, _stream()), "rvit_batch_sum_f32")
     return out
