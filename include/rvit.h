@@ -160,6 +160,32 @@ int rvit_colsum_bf16(const void* a, int64_t lda, float* out, int64_t M, int N, i
  * over the batch; backward of the broadcast add at train_vit.py:155-159). */
 int rvit_batch_sum_f32(const float* x, int64_t ldb, float* out, int B, int64_t n, void* stream);
 
+/* Training-mode BatchNorm2d on NHWC bf16 maps viewed as [M = B*H*W, C] (timm resnet BatchNorm2d
+ * in train(), train_vit.py:87; eps inside the sqrt, biased batch variance for normalisation,
+ * unbiased for running_var, momentum update like torch).  C % 8 == 0, 256 % (C/8) == 0.
+ *   rvit_bn_stats:  sums[0..C) += sum_m y, sums[C..2C) += sum_m y^2   (caller zeroes sums)
+ *   rvit_bn_apply:  z = relu?( gamma*(y-mean)*rstd + beta + residual ); updates running stats
+ *                   when running_mean/var are given. */
+int rvit_bn_stats(const void* y, int64_t M, int C, float* sums, void* stream);
+int rvit_bn_apply(const void* y, const float* sums, const float* gamma, const float* beta, const void* residual,
+                  void* z, int64_t M, int C, float eps, int relu, float momentum, float* running_mean,
+                  float* running_var, void* stream);
+
+/* Backward of the above (autograd of BatchNorm2d + ReLU + residual add):
+ *   dzm = dz * (z > 0) when relu, else dz
+ *   rvit_bn_bwd_reduce: bwd_sums[0..C) += sum dzm, bwd_sums[C..2C) += sum dzm*xhat (caller zeroes)
+ *   rvit_bn_bwd_apply:  dy = gamma*rstd*(dzm - mean(dzm) - xhat*mean(dzm*xhat)); dgamma += .., dbeta += ..;
+ *                       dz_masked (optional) receives dzm = the gradient of the residual branch. */
+int rvit_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* fwd_sums, int64_t M, int C,
+                       float eps, int relu, float* bwd_sums, void* stream);
+int rvit_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* fwd_sums, const float* bwd_sums,
+                      const float* gamma, void* dy, void* dz_masked, float* dgamma, float* dbeta, int64_t M, int C,
+                      float eps, int relu, void* stream);
+
+/* Backward of rvit_maxpool3x3s2_nhwc from the recorded argmax taps; dx bf16 [B,H,W,C]. */
+int rvit_maxpool3x3s2_bwd_nhwc(const void* dpool, const void* argmax, void* dx, int B, int H, int W, int C,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

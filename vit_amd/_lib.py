@@ -48,6 +48,11 @@ SIGNATURES = {
     "rvit_ce_loss": ([P, L, P, P, P, L, P, L, I, I, I, F, F, P], c_int),
     "rvit_colsum_bf16": ([P, L, P, L, I, L, L, P], c_int),
     "rvit_batch_sum_f32": ([P, L, P, I, L, P], c_int),
+    "rvit_bn_stats": ([P, L, I, P, P], c_int),
+    "rvit_bn_apply": ([P, P, P, P, P, P, L, I, F, I, F, P, P, P], c_int),
+    "rvit_bn_bwd_reduce": ([P, P, P, P, L, I, F, I, P, P], c_int),
+    "rvit_bn_bwd_apply": ([P, P, P, P, P, P, P, P, P, P, L, I, F, I, P], c_int),
+    "rvit_maxpool3x3s2_bwd_nhwc": ([P, P, P, I, I, I, I, P], c_int),
 }
 
 _lib = None

@@ -1,0 +1,36 @@
+// extern "C" surface, part 2: training-mode BatchNorm and max-pool backward (bn.hip).
+#include "../../include/rvit.h"
+#include "common.h"
+#include "rvit_internal.h"
+
+extern "C" {
+
+int rvit_bn_stats(const void* y, int64_t M, int C, float* sums, void* stream) {
+  return rvit_bn_stats_impl(y, M, C, sums, (hipStream_t)stream);
+}
+
+int rvit_bn_apply(const void* y, const float* sums, const float* gamma, const float* beta, const void* residual,
+                  void* z, int64_t M, int C, float eps, int relu, float momentum, float* running_mean,
+                  float* running_var, void* stream) {
+  return rvit_bn_apply_impl(y, sums, gamma, beta, residual, z, M, C, eps, relu, momentum, running_mean, running_var,
+                            (hipStream_t)stream);
+}
+
+int rvit_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* fwd_sums, int64_t M, int C,
+                       float eps, int relu, float* bwd_sums, void* stream) {
+  return rvit_bn_bwd_reduce_impl(dz, z, y, fwd_sums, M, C, eps, relu, bwd_sums, (hipStream_t)stream);
+}
+
+int rvit_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* fwd_sums, const float* bwd_sums,
+                      const float* gamma, void* dy, void* dz_masked, float* dgamma, float* dbeta, int64_t M, int C,
+                      float eps, int relu, void* stream) {
+  return rvit_bn_bwd_apply_impl(dz, z, y, fwd_sums, bwd_sums, gamma, dy, dz_masked, dgamma, dbeta, M, C, eps, relu,
+                                (hipStream_t)stream);
+}
+
+int rvit_maxpool3x3s2_bwd_nhwc(const void* dpool, const void* argmax, void* dx, int B, int H, int W, int C,
+                               void* stream) {
+  return rvit_maxpool_bwd_impl(dpool, argmax, dx, B, H, W, C, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -182,6 +182,7 @@ class CNNViTHybrid(nn.Module):
         self.head = nn.ModuleDict({"0": _Linear(embed_dim, embed_dim // 2), "3": _Linear(embed_dim // 2, num_classes)})
         self._init_weights()
         self._engine = None
+        self._train_engine = None
 
     def _init_weights(self):  # train_vit.py:132-139
         nn.init.trunc_normal_(self.pos_embed, std=0.02)
@@ -205,13 +206,34 @@ class CNNViTHybrid(nn.Module):
                                "input to a cuda device. There is no CPU fallback.")
         return x
 
+    @property
+    def train_engine(self):
+        if self._train_engine is None:
+            from .trainer import TrainEngine
+            object.__setattr__(self, "_train_engine", TrainEngine(self))
+        return self._train_engine
+
+    def set_data_parallel(self, process_group=None, bucket_mb: float = 25.0) -> None:
+        """Average gradients over `process_group` (RCCL) in buckets overlapped with backward."""
+        self.train_engine.set_data_parallel(process_group, bucket_mb)
+
+    def _run(self, x, features_only: bool):
+        x = self._check_input(x)
+        if self.training:
+            # train(): BatchNorm batch statistics; backward on librvit when gradients are recorded
+            from .trainer import HybridFunction
+            if torch.is_grad_enabled():
+                return HybridFunction.apply(x, self.train_engine, features_only, *self.parameters())
+            return self.train_engine.forward(x, features_only)
+        return self.engine.run(x, features_only)
+
     def forward(self, x):
         """[B,3,224,224] float (ImageNet-normalised, NCHW) -> fp32 logits [B,num_classes]."""
-        return self.engine.run(self._check_input(x), features_only=False)
+        return self._run(x, False)
 
     def forward_features(self, x):
         """-> fp32 cls-token features [B,embed_dim] (train_vit.py:173-185)."""
-        return self.engine.run(self._check_input(x), features_only=True)
+        return self._run(x, True)
 
     def config(self) -> Dict:
         """`model_config` entry of the checkpoint dict (train_vit.py:999-1007)."""

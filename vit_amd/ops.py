@@ -430,3 +430,78 @@ def batch_sum(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     with _Span("batch_sum", 0, B * n * 4):
         check(_lib.load().rvit_batch_sum_f32(x.data_ptr(), ldb, out.data_ptr(), B, n, _stream()), "rvit_batch_sum_f32")
     return out
+
+
+# =================================================================================================
+# training-mode BatchNorm (+ residual + ReLU) and max-pool backward
+# =================================================================================================
+def _map2d(t: torch.Tensor, what: str):
+    if t.dtype != BF16 or not t.is_contiguous() or t.dim() < 2:
+        raise ValueError(f"{what}: contiguous bf16 NHWC map required")
+    C = t.shape[-1]
+    return t.numel() // C, C
+
+
+def bn_stats(y: torch.Tensor, sums: torch.Tensor) -> torch.Tensor:
+    """sums[0:C] += sum y, sums[C:2C] += sum y^2 over all pixels; y bf16 [...,C]."""
+    _need_cuda(y, sums)
+    M, C = _map2d(y, "bn_stats y")
+    _vec_f32(sums, 2 * C, "bn_stats: sums")
+    with _Span("bn_stats", 0, M * C * 2):
+        check(_lib.load().rvit_bn_stats(y.data_ptr(), M, C, sums.data_ptr(), _stream()), "rvit_bn_stats")
+    return sums
+
+
+def bn_apply(y: torch.Tensor, sums: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, z: torch.Tensor, *,
+             eps: float, relu: bool, residual: Optional[torch.Tensor] = None, momentum: float = 0.1,
+             running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(y, sums, gamma, beta, z, residual, running_mean, running_var)
+    M, C = _map2d(y, "bn_apply y")
+    if z.shape != y.shape or _map2d(z, "bn_apply z") != (M, C) or (residual is not None and residual.shape != y.shape):
+        raise ValueError("bn_apply: shape mismatch")
+    if residual is not None:
+        _map2d(residual, "bn_apply residual")
+    for v, n in ((sums, 2 * C), (gamma, C), (beta, C), (running_mean, C), (running_var, C)):
+        _vec_f32(v, n, "bn_apply: vector")
+    with _Span("bn_apply", 0, _nbytes(y, z, residual)):
+        check(_lib.load().rvit_bn_apply(y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                        _ptr(residual), z.data_ptr(), M, C, eps, int(relu), momentum,
+                                        _ptr(running_mean), _ptr(running_var), _stream()), "rvit_bn_apply")
+    return z
+
+
+def bn_bwd(dz: torch.Tensor, z: Optional[torch.Tensor], y: torch.Tensor, fwd_sums: torch.Tensor,
+           bwd_sums: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, *,
+           eps: float, relu: bool, dz_masked: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Both BatchNorm backward passes (reduce, then apply); bwd_sums must be zero on entry."""
+    _need_cuda(dz, z, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, dz_masked)
+    M, C = _map2d(y, "bn_bwd y")
+    for t in (dz, dy, z, dz_masked):
+        if t is not None and (t.shape != y.shape or _map2d(t, "bn_bwd map") != (M, C)):
+            raise ValueError("bn_bwd: shape mismatch")
+    if relu and z is None:
+        raise ValueError("bn_bwd: relu needs the forward output z")
+    for v, n in ((fwd_sums, 2 * C), (bwd_sums, 2 * C), (gamma, C), (dgamma, C), (dbeta, C)):
+        _vec_f32(v, n, "bn_bwd: vector")
+    lib = _lib.load()
+    with _Span("bn_bwd_reduce", 0, _nbytes(dz, y, z if relu else None)):
+        check(lib.rvit_bn_bwd_reduce(dz.data_ptr(), _ptr(z), y.data_ptr(), fwd_sums.data_ptr(), M, C, eps, int(relu),
+                                     bwd_sums.data_ptr(), _stream()), "rvit_bn_bwd_reduce")
+    with _Span("bn_bwd_apply", 0, _nbytes(dz, y, z if relu else None, dy, dz_masked)):
+        check(lib.rvit_bn_bwd_apply(dz.data_ptr(), _ptr(z), y.data_ptr(), fwd_sums.data_ptr(), bwd_sums.data_ptr(),
+                                    gamma.data_ptr(), dy.data_ptr(), _ptr(dz_masked), dgamma.data_ptr(),
+                                    dbeta.data_ptr(), M, C, eps, int(relu), _stream()), "rvit_bn_bwd_apply")
+    return dy
+
+
+def maxpool3x3s2_bwd(dpool: torch.Tensor, argmax: torch.Tensor, dx: torch.Tensor) -> torch.Tensor:
+    _need_cuda(dpool, argmax, dx)
+    B, H, W, C = dx.shape
+    if dpool.shape != argmax.shape or dpool.dtype != BF16 or dx.dtype != BF16 or argmax.dtype != torch.uint8 \
+            or not (dpool.is_contiguous() and dx.is_contiguous() and argmax.is_contiguous()) \
+            or tuple(dpool.shape) != (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C):
+        raise ValueError("maxpool3x3s2_bwd: bad operands")
+    with _Span("maxpool_bwd", 0, _nbytes(dpool, argmax, dx)):
+        check(_lib.load().rvit_maxpool3x3s2_bwd_nhwc(dpool.data_ptr(), argmax.data_ptr(), dx.data_ptr(), B, H, W, C,
+                                                     _stream()), "rvit_maxpool3x3s2_bwd_nhwc")
+    return dx

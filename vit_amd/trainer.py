@@ -1,0 +1,520 @@
+"""Training path of `CNNViTHybrid`: forward with saved activations + hand-scheduled backward on
+librvit kernels (autograd of train_vit.py:141-171 as run by `loss.backward()`, train_vit.py:939),
+exposed to PyTorch through one `torch.autograd.Function`, plus the data-parallel gradient exchange.
+
+Gradients of ALL parameters are produced in ONE flat fp32 buffer laid out in the order the backward
+pass finishes them (head first, stem conv1 last).  Under data parallelism the flat buffer is cut
+into buckets that are all-reduced (RCCL, averaged) on a side stream as soon as the backward has
+written them, overlapping communication with the rest of the backward.
+
+Precision: bf16 operands / fp32 accumulation everywhere, fp32 master weights and fp32 gradients,
+no loss scaling (deviation from the reference's fp16 autocast + GradScaler, train_vit.py:896,935;
+stated in SURVEY.md §8a row 16).  BatchNorm uses per-replica batch statistics (no SyncBN in the
+reference).  Dropout (train_vit.py:100,107,125) is applied only when p == 0 is NOT requested:
+see `_dropout_supported`.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _t(w: torch.Tensor) -> torch.Tensor:
+    return w.detach().t().to(BF16).contiguous()
+
+
+def _b(w: torch.Tensor) -> torch.Tensor:
+    return w.detach().to(BF16).contiguous()
+
+
+def _conv_fwd_pack(w: torch.Tensor) -> torch.Tensor:   # [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin]
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(BF16).contiguous()
+
+
+def _conv_bwd_pack(w: torch.Tensor) -> torch.Tensor:   # [Cout,Cin,kh,kw] -> [Cin, kh*kw*Cout]
+    return w.detach().permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(BF16).contiguous()
+
+
+def _px4_pack(w: torch.Tensor, kw_pad: int) -> torch.Tensor:
+    cout, cin, kh, kw = w.shape
+    p = torch.zeros(cout, kh, kw_pad, 4, dtype=F32, device=w.device)
+    p[:, :, :kw, :cin] = w.detach().permute(0, 2, 3, 1)
+    return p.reshape(cout, -1).to(BF16).contiguous()
+
+
+class _GradLayout:
+    """Flat fp32 gradient buffer: one segment per parameter, in backward-completion order."""
+
+    def __init__(self, model):
+        named = dict(model.named_parameters())
+        order: List[str] = ["head.3.weight", "head.3.bias", "head.0.weight", "head.0.bias", "norm.weight", "norm.bias"]
+        for i in reversed(range(model.num_layers)):
+            p = f"transformer.layers.{i}."
+            order += [p + "linear2.weight", p + "linear2.bias", p + "linear1.weight", p + "linear1.bias",
+                      p + "norm2.weight", p + "norm2.bias", p + "self_attn.out_proj.weight",
+                      p + "self_attn.out_proj.bias", p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias",
+                      p + "norm1.weight", p + "norm1.bias"]
+        order += ["pos_embed", "cls_token", "patch_embed.weight", "patch_embed.bias"]
+        if model.cnn_backbone is not None:
+            stem = [n for n in named if n.startswith("cnn_backbone.")]
+            # reverse module order: layer4.1 ... layer1.0, then conv1/bn1
+            order += list(reversed(stem))
+        assert set(order) == set(named), set(named) ^ set(order)
+        self.names = order
+        self.offsets: Dict[str, Tuple[int, int, torch.Size]] = {}
+        off = 0
+        for n in order:
+            numel = named[n].numel()
+            self.offsets[n] = (off, numel, named[n].shape)
+            off += (numel + 63) // 64 * 64  # 256-byte aligned segments
+        self.total = off
+        self.param_order = [n for n, _ in model.named_parameters()]
+
+
+class TrainEngine:
+    def __init__(self, model):
+        self.m = model
+        self.layout = _GradLayout(model)
+        self._pack = None
+        self._pack_key = None
+        self._bufs: Dict[int, dict] = {}
+        self.process_group = None
+        self.world_size = 1
+        self.bucket_bytes = 25 << 20
+        self._comm_stream = None
+        self._reduced_upto = 0
+
+    # ---- data parallel -------------------------------------------------------------------------
+    def set_data_parallel(self, process_group=None, bucket_mb: float = 25.0) -> None:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.process_group = process_group if process_group is not None else dist.group.WORLD
+        self.world_size = dist.get_world_size(self.process_group)
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+
+    # ---- packing ---------------------------------------------------------------------------------
+    def _key(self):
+        ps = list(self.m.parameters())
+        return (tuple(p._version for p in ps), ps[0].data_ptr())
+
+    @torch.no_grad()
+    def pack(self) -> dict:
+        key = self._key()
+        if self._pack is not None and key == self._pack_key:
+            return self._pack
+        m = self.m
+        P: dict = {}
+        if m.cnn_backbone is not None:
+            cb = m.cnn_backbone
+            P["conv1_w"] = _px4_pack(cb.conv1.weight, 8)
+            blocks = []
+            for blk in cb.blocks():
+                d = {"stride": blk.conv1.stride, "cin": blk.conv1.cin, "cout": blk.conv1.cout,
+                     "c1_w": _conv_fwd_pack(blk.conv1.weight), "c1_wt": _conv_bwd_pack(blk.conv1.weight),
+                     "c2_w": _conv_fwd_pack(blk.conv2.weight), "c2_wt": _conv_bwd_pack(blk.conv2.weight)}
+                if blk.downsample is not None:
+                    d["ds_w"] = _conv_fwd_pack(blk.downsample["0"].weight)
+                    d["ds_wt"] = _conv_bwd_pack(blk.downsample["0"].weight)
+                blocks.append(d)
+            P["blocks"] = blocks
+            pw = m.patch_embed.weight.detach().reshape(m.embed_dim, -1)
+            P["pe_w"], P["pe_wt"] = _b(pw), _t(pw)
+        else:
+            P["pe_w"] = _px4_pack(m.patch_embed.weight, 16)
+        layers = []
+        for L in m.transformer.layers:
+            layers.append(dict(qkv_w=_b(L.self_attn.in_proj_weight), qkv_wt=_t(L.self_attn.in_proj_weight),
+                               out_w=_b(L.self_attn.out_proj.weight), out_wt=_t(L.self_attn.out_proj.weight),
+                               fc1_w=_b(L.linear1.weight), fc1_wt=_t(L.linear1.weight),
+                               fc2_w=_b(L.linear2.weight), fc2_wt=_t(L.linear2.weight)))
+        P["layers"] = layers
+        P["h0_w"], P["h0_wt"] = _b(m.head["0"].weight), _t(m.head["0"].weight)
+        P["h3_w"] = _b(m.head["3"].weight)
+        h3t = torch.zeros(m.embed_dim // 2, 16 * ((m.num_classes + 15) // 16), dtype=BF16, device=m.pos_embed.device)
+        h3t[:, : m.num_classes] = m.head["3"].weight.detach().t().to(BF16)
+        P["h3_wt"] = h3t
+        self._pack, self._pack_key = P, key
+        return P
+
+    # ---- buffers -----------------------------------------------------------------------------------
+    def buffers(self, B: int, dev) -> dict:
+        b = self._bufs.get(B)
+        if b is not None and b["dev"] == dev:
+            return b
+        self._bufs.clear()
+        m = self.m
+        E, S, H, Lr = m.embed_dim, m.num_patches + 1, m.num_heads, m.num_layers
+        T = B * S
+        z = dict(dtype=BF16, device=dev)
+        f = dict(dtype=F32, device=dev)
+        b = {"dev": dev}
+        if m.cnn_backbone is not None:
+            b["img"] = torch.zeros(B, 230, 232, 4, **z)
+            b["c1_y"] = torch.empty(B, 112, 112, 64, **z)
+            b["c1_z"] = torch.empty(B, 112, 112, 64, **z)
+            b["pool"] = torch.empty(B, 56, 56, 64, **z)
+            b["pool_arg"] = torch.empty(B, 56, 56, 64, dtype=torch.uint8, device=dev)
+            blocks = []
+            hw = 56
+            nsum = 128  # conv1 bn sums
+            for blk in m.cnn_backbone.blocks():
+                s, co = blk.conv1.stride, blk.conv1.cout
+                hw //= s
+                d = {nm: torch.empty(B, hw, hw, co, **z) for nm in ("y1", "z1", "y2", "zo")}
+                if blk.downsample is not None:
+                    d["yd"] = torch.empty(B, hw, hw, co, **z)
+                    d["zd"] = torch.empty(B, hw, hw, co, **z)
+                blocks.append(d)
+                nsum += 2 * co * (3 if blk.downsample is not None else 2)
+            b["blocks"] = blocks
+            b["fsums"] = torch.zeros(nsum, **f)
+            b["bsums"] = torch.zeros(nsum, **f)
+            # scratch maps for the stem backward, sized per stage on demand
+            b["scratch"] = {}
+        else:
+            b["img"] = torch.zeros(B, 224, 224, 4, **z)
+        b["xs"] = [torch.empty(B, S, E, **f) for _ in range(2 * Lr + 1)]
+        b["stat"] = torch.empty(Lr, 4, T, **f)
+        b["ln1"] = [torch.empty(T, E, **z) for _ in range(Lr)]
+        b["ln2"] = [torch.empty(T, E, **z) for _ in range(Lr)]
+        b["qkv"] = [torch.empty(T, 3 * E, **z) for _ in range(Lr)]
+        b["att"] = [torch.empty(T, E, **z) for _ in range(Lr)]
+        b["lse"] = [torch.empty(B * H * S, **f) for _ in range(Lr)]
+        b["u"] = [torch.empty(T, 4 * E, **z) for _ in range(Lr)]
+        b["h"] = [torch.empty(T, 4 * E, **z) for _ in range(Lr)]
+        b["cls_stat"] = torch.empty(2, B, **f)
+        b["cls_ln"] = torch.empty(B, E, **z)
+        b["u0"] = torch.empty(B, E // 2, **z)
+        b["h0"] = torch.empty(B, E // 2, **z)
+        # backward scratch
+        b["dxs"] = torch.empty(B, S, E, **f)
+        b["dxs_bf"] = torch.empty(T, E, **z)
+        b["d_e"] = torch.empty(T, E, **z)
+        b["d_3e"] = torch.empty(T, 3 * E, **z)
+        b["d_4e"] = torch.empty(T, 4 * E, **z)
+        b["d_h0"] = torch.empty(B, E // 2, **z)
+        b["d_cls"] = torch.empty(B, E, **z)
+        b["dl16"] = torch.zeros(B, 16 * ((m.num_classes + 15) // 16), **z)
+        b["tmp16"] = torch.zeros(16 * ((m.num_classes + 15) // 16), **f)
+        self._bufs[B] = b
+        return b
+
+    def _scratch(self, b, key, like: torch.Tensor) -> torch.Tensor:
+        t = b["scratch"].get(key)
+        if t is None or t.shape != like.shape:
+            t = torch.empty_like(like)
+            b["scratch"][key] = t
+        return t
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def _bn_params(self, bn):
+        return bn.weight.detach(), bn.bias.detach()
+
+    def _conv_bn(self, x, w, y, z, bn, fs, *, kh, stride, pad, relu, residual=None, seg_len=None, kw=None):
+        ops.conv2d(x, w, y, kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, seg_len=seg_len)
+        ops.bn_stats(y, fs)
+        ops.bn_apply(y, fs, bn.weight.detach(), bn.bias.detach(), z, eps=bn.eps, relu=relu, residual=residual,
+                     momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var)
+        bn.num_batches_tracked += 1
+
+    def _stem_forward(self, P, b, B) -> torch.Tensor:
+        cb = self.m.cnn_backbone
+        b["fsums"].zero_()
+        off = 0
+        fs = b["fsums"]
+        self._conv_bn(b["img"], P["conv1_w"], b["c1_y"], b["c1_z"], cb.bn1, fs[off:off + 128], kh=7, kw=1, stride=2,
+                      pad=0, relu=True, seg_len=32)
+        off += 128
+        ops.maxpool3x3s2(b["c1_z"], b["pool"], b["pool_arg"])
+        cur = b["pool"]
+        for blk, pk, d in zip(cb.blocks(), P["blocks"], b["blocks"]):
+            s, co = pk["stride"], pk["cout"]
+            d["in"] = cur
+            d["fs_off"] = off
+            self._conv_bn(cur, pk["c1_w"], d["y1"], d["z1"], blk.bn1, fs[off:off + 2 * co], kh=3, stride=s, pad=1,
+                          relu=True)
+            off += 2 * co
+            idn = cur
+            if "ds_w" in pk:
+                self._conv_bn(cur, pk["ds_w"], d["yd"], d["zd"], blk.downsample["1"], fs[off + 2 * co:off + 4 * co],
+                              kh=1, stride=s, pad=0, relu=False)
+                idn = d["zd"]
+            self._conv_bn(d["z1"], pk["c2_w"], d["y2"], d["zo"], blk.bn2, fs[off:off + 2 * co], kh=3, stride=1, pad=1,
+                          relu=True, residual=idn)
+            off += 2 * co * (2 if "ds_w" in pk else 1)
+            cur = d["zo"]
+        return cur
+
+    def forward(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
+        m = self.m
+        if m.dropout != 0.0:
+            raise NotImplementedError(
+                "training through librvit currently requires dropout=0.0 (the six dropout sites of the reference, "
+                "train_vit.py:100,107,125, are not implemented on the HIP path yet); construct the model with "
+                "dropout=0.0")
+        P = self.pack()
+        B = x.shape[0]
+        E, S, H, NP = m.embed_dim, m.num_patches + 1, m.num_heads, m.num_patches
+        T = B * S
+        b = self.buffers(B, x.device)
+        xin = x.detach().float().contiguous()
+        xs = b["xs"]
+        x0 = xs[0]
+        if m.cnn_backbone is not None:
+            ops.input_pack(xin, b["img"], 3, 3)
+            feat = self._stem_forward(P, b, B)
+            b["feat"] = feat
+            ops.gemm(feat.view(B * NP, -1), P["pe_w"], x0.view(T, E), bias=m.patch_embed.bias.detach(),
+                     residual=m.pos_embed.detach().view(S, E)[1:], residual_period=NP, row_group=NP, row_extra=1)
+        else:
+            ops.input_pack(xin, b["img"], 0, 0)
+            ops.conv2d_tokens(b["img"], P["pe_w"], x0, m.pos_embed.detach().view(S, E), kh=16, kw=1, stride=16, pad=0,
+                              seg_len=64, ho=14, wo=14, bias=m.patch_embed.bias.detach())
+        ops.embed_cls(m.cls_token.detach().view(-1), m.pos_embed.detach().view(S, E), x0)
+        for i, (L, W) in enumerate(zip(m.transformer.layers, P["layers"])):
+            xi, xm, xo = xs[2 * i].view(T, E), xs[2 * i + 1].view(T, E), xs[2 * i + 2].view(T, E)
+            st = b["stat"][i]
+            ops.layernorm(xi, L.norm1.weight.detach(), L.norm1.bias.detach(), b["ln1"][i], L.norm1.eps, st[0], st[1])
+            ops.gemm(b["ln1"][i], W["qkv_w"], b["qkv"][i], bias=L.self_attn.in_proj_bias.detach())
+            ops.attention(b["qkv"][i], b["att"][i], B, S, H, lse=b["lse"][i])
+            ops.gemm(b["att"][i], W["out_w"], xm, bias=L.self_attn.out_proj.bias.detach(), residual=xi)
+            ops.layernorm(xm, L.norm2.weight.detach(), L.norm2.bias.detach(), b["ln2"][i], L.norm2.eps, st[2], st[3])
+            ops.gemm(b["ln2"][i], W["fc1_w"], b["h"][i], bias=L.linear1.bias.detach(), act="gelu", preact=b["u"][i])
+            ops.gemm(b["h"][i], W["fc2_w"], xo, bias=L.linear2.bias.detach(), residual=xm)
+        xf = xs[-1]
+        cls_rows = xf.view(B, S * E)[:, :E]
+        cs = b["cls_stat"]
+        if features_only:
+            out = torch.empty(B, E, dtype=F32, device=x.device)
+            ops.layernorm(cls_rows, m.norm.weight.detach(), m.norm.bias.detach(), out, m.norm.eps, cs[0], cs[1])
+            return out
+        ops.layernorm(cls_rows, m.norm.weight.detach(), m.norm.bias.detach(), b["cls_ln"], m.norm.eps, cs[0], cs[1])
+        ops.gemm(b["cls_ln"], P["h0_w"], b["h0"], bias=m.head["0"].bias.detach(), act="gelu", preact=b["u0"])
+        logits = torch.empty(B, m.num_classes, dtype=F32, device=x.device)
+        ops.gemm(b["h0"], P["h3_w"], logits, bias=m.head["3"].bias.detach())
+        return logits
+
+    # ---- backward ----------------------------------------------------------------------------------
+    def _g(self, flat, name) -> torch.Tensor:
+        off, n, shape = self.layout.offsets[name]
+        return flat[off:off + n]
+
+    def _g2(self, flat, name, rows) -> torch.Tensor:
+        return self._g(flat, name).view(rows, -1)
+
+    def _stem_backward(self, P, b, B, flat, dfeat: torch.Tensor) -> None:
+        cb = self.m.cnn_backbone
+        b["bsums"].zero_()
+        bs_all, fs_all = b["bsums"], b["fsums"]
+        dz = dfeat
+        blocks = list(zip(list(cb.blocks()), P["blocks"], b["blocks"],
+                          [n for n in self._block_names()]))
+        for blk, pk, d, pref in reversed(blocks):
+            s, co, ci = pk["stride"], pk["cout"], pk["cin"]
+            off = d["fs_off"]
+            has_ds = "ds_w" in pk
+            # sums layout per block (see _stem_forward): [bn1 | bn2 | downsample bn]
+            f1, f2 = fs_all[off:off + 2 * co], fs_all[off + 2 * co:off + 4 * co]
+            fd = fs_all[off + 4 * co:off + 6 * co] if has_ds else None
+            b1, b2 = bs_all[off:off + 2 * co], bs_all[off + 2 * co:off + 4 * co]
+            bd = bs_all[off + 4 * co:off + 6 * co] if has_ds else None
+            dy2 = self._scratch(b, ("dy", co, d["y2"].shape[1]), d["y2"])
+            dzm = self._scratch(b, ("dzm", co, d["y2"].shape[1]), d["y2"])
+            ops.bn_bwd(dz, d["zo"], d["y2"], f2, b2, blk.bn2.weight.detach(), dy2,
+                       self._g(flat, pref + "bn2.weight"), self._g(flat, pref + "bn2.bias"), eps=blk.bn2.eps, relu=True,
+                       dz_masked=dzm)
+            ops.conv2d_wgrad(dy2, d["z1"], self._g(flat, pref + "conv2.weight").view(co, 9 * co), kh=3, kw=3, stride=1,
+                             pad=1)
+            dz1 = self._scratch(b, ("dz1", co, d["y2"].shape[1]), d["y2"])
+            ops.conv2d_dgrad(dy2, pk["c2_wt"], dz1, kh=3, kw=3, stride=1, pad=1)
+            dy1 = dy2  # dy2 is dead now
+            ops.bn_bwd(dz1, d["z1"], d["y1"], f1, b1, blk.bn1.weight.detach(), dy1,
+                       self._g(flat, pref + "bn1.weight"), self._g(flat, pref + "bn1.bias"), eps=blk.bn1.eps, relu=True)
+            xin = d["in"]
+            ops.conv2d_wgrad(dy1, xin, self._g(flat, pref + "conv1.weight").view(co, 9 * ci), kh=3, kw=3, stride=s,
+                             pad=1)
+            dxin = self._scratch(b, ("dx", ci, xin.shape[1]), xin)
+            if has_ds:
+                dyd = dz1  # dz1 is dead now
+                ops.bn_bwd(dzm, None, d["yd"], fd, bd, blk.downsample["1"].weight.detach(), dyd,
+                           self._g(flat, pref + "downsample.1.weight"), self._g(flat, pref + "downsample.1.bias"),
+                           eps=blk.downsample["1"].eps, relu=False)
+                ops.conv2d_wgrad(dyd, xin, self._g(flat, pref + "downsample.0.weight").view(co, ci), kh=1, kw=1,
+                                 stride=s, pad=0)
+                tmp = self._scratch(b, ("dxt", ci, xin.shape[1]), xin)
+                ops.conv2d_dgrad(dyd, pk["ds_wt"], tmp, kh=1, kw=1, stride=s, pad=0)
+                ops.conv2d_dgrad(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=s, pad=1, residual=tmp)
+            else:
+                ops.conv2d_dgrad(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=s, pad=1, residual=dzm)
+            dz = dxin
+        # max-pool and the 7x7 stem conv (its input is the image: no dgrad)
+        dc1 = self._scratch(b, ("dc1",), b["c1_z"])
+        ops.maxpool3x3s2_bwd(dz, b["pool_arg"], dc1)
+        dyc = self._scratch(b, ("dyc",), b["c1_z"])
+        ops.bn_bwd(dc1, b["c1_z"], b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(), dyc,
+                   self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"), eps=cb.bn1.eps,
+                   relu=True)
+        dw1 = torch.zeros(64, 224, dtype=F32, device=dyc.device)
+        ops.conv2d_wgrad(dyc, b["img"], dw1, kh=7, kw=1, stride=2, pad=0, seg_len=32)
+        self._g(flat, "cnn_backbone.conv1.weight").view(64, 7, 7, 3).copy_(dw1.view(64, 7, 8, 4)[:, :, :7, :3])
+
+    def _block_names(self):
+        cb = self.m.cnn_backbone
+        for li in range(1, 5):
+            for bi in range(len(getattr(cb, f"layer{li}"))):
+                yield f"cnn_backbone.layer{li}.{bi}."
+
+    def backward(self, dout: torch.Tensor, features_only: bool, B: int) -> torch.Tensor:
+        """dout: gradient of the logits [B,C] (or of the features [B,E]); returns the flat grad buffer."""
+        m = self.m
+        P = self.pack()
+        b = self._bufs[B]
+        dev = dout.device
+        E, S, H, NP, C = m.embed_dim, m.num_patches + 1, m.num_heads, m.num_patches, m.num_classes
+        T = B * S
+        L = self.layout
+        flat = torch.zeros(L.total, dtype=F32, device=dev)
+        g, g2 = lambda n: self._g(flat, n), lambda n, r: self._g2(flat, n, r)  # noqa: E731
+        dxs, dxs_bf = b["dxs"], b["dxs_bf"]
+        dxs.zero_()
+        dxs_bf.zero_()
+        cs = b["cls_stat"]
+        xs = b["xs"]
+        cls_rows = xs[-1].view(B, S * E)[:, :E]
+        dx_cls = dxs.view(B, S * E)[:, :E]
+        dxb_cls = dxs_bf.view(B, S * E)[:, :E]
+        if features_only:
+            dcls = dout.to(BF16).contiguous()
+        else:
+            dl16 = b["dl16"]
+            dl16[:, :C].copy_(dout)
+            ops.wgrad(dl16, b["h0"], g2("head.3.weight", C), n_store=C)
+            b["tmp16"].zero_()
+            ops.colsum(dl16, b["tmp16"])
+            g("head.3.bias").copy_(b["tmp16"][:C])
+            ops.gemm(dl16, P["h3_wt"], b["d_h0"], gate=b["u0"], gate_mode="gelu_grad")
+            ops.wgrad(b["d_h0"], b["cls_ln"], g2("head.0.weight", E // 2))
+            ops.colsum(b["d_h0"], g("head.0.bias"))
+            dcls = ops.gemm(b["d_h0"], P["h0_wt"], b["d_cls"])
+        ops.layernorm_bwd(dcls, cls_rows, cs[0], cs[1], m.norm.weight.detach(), dx_cls, g("norm.weight"),
+                          g("norm.bias"), accumulate=False, dx_bf16=dxb_cls)
+        self._maybe_reduce(flat, "norm.bias")
+        dx2 = dxs.view(T, E)
+        for i in reversed(range(m.num_layers)):
+            Lm, W = m.transformer.layers[i], P["layers"][i]
+            p = f"transformer.layers.{i}."
+            xi, xm = xs[2 * i].view(T, E), xs[2 * i + 1].view(T, E)
+            st = b["stat"][i]
+            # ---- MLP block:  xo = xm + fc2(gelu(fc1(LN2(xm))))
+            ops.wgrad(dxs_bf, b["h"][i], g2(p + "linear2.weight", E))
+            ops.colsum(dxs_bf, g(p + "linear2.bias"))
+            ops.gemm(dxs_bf, W["fc2_wt"], b["d_4e"], gate=b["u"][i], gate_mode="gelu_grad")
+            ops.wgrad(b["d_4e"], b["ln2"][i], g2(p + "linear1.weight", 4 * E))
+            ops.colsum(b["d_4e"], g(p + "linear1.bias"))
+            ops.gemm(b["d_4e"], W["fc1_wt"], b["d_e"])
+            ops.layernorm_bwd(b["d_e"], xm, st[2], st[3], Lm.norm2.weight.detach(), dx2, g(p + "norm2.weight"),
+                              g(p + "norm2.bias"), accumulate=True, dx_bf16=dxs_bf)
+            # ---- attention block:  xm = xi + out_proj(attn(qkv(LN1(xi))))
+            ops.wgrad(dxs_bf, b["att"][i], g2(p + "self_attn.out_proj.weight", E))
+            ops.colsum(dxs_bf, g(p + "self_attn.out_proj.bias"))
+            ops.gemm(dxs_bf, W["out_wt"], b["d_e"])
+            ops.attention_bwd(b["qkv"][i], b["att"][i], b["d_e"], b["lse"][i], b["d_3e"], B, S, H)
+            ops.wgrad(b["d_3e"], b["ln1"][i], g2(p + "self_attn.in_proj_weight", 3 * E))
+            ops.colsum(b["d_3e"], g(p + "self_attn.in_proj_bias"))
+            ops.gemm(b["d_3e"], W["qkv_wt"], b["d_e"])
+            ops.layernorm_bwd(b["d_e"], xi, st[0], st[1], Lm.norm1.weight.detach(), dx2, g(p + "norm1.weight"),
+                              g(p + "norm1.bias"), accumulate=True, dx_bf16=dxs_bf)
+            self._maybe_reduce(flat, p + "norm1.bias")
+        # ---- token assembly: x0[b,0] = cls + pos[0]; x0[b,1+p] = patch[b,p] + pos[1+p]
+        ops.batch_sum(dxs.view(B, S * E), g("pos_embed"))
+        g("cls_token").copy_(g("pos_embed")[:E])
+        if m.cnn_backbone is not None:
+            feat = b["feat"]
+            ops.wgrad(dxs_bf, feat.view(B * NP, -1), g2("patch_embed.weight", E), rows=B * NP, y_row_group=NP,
+                      y_row_extra=1)
+            ops.colsum(dxs_bf, g("patch_embed.bias"), rows=B * NP, row_group=NP, row_extra=1)
+            dfeat = self._scratch(b, ("dfeat",), feat)
+            ops.gemm(dxs_bf, P["pe_wt"], dfeat.view(B * NP, -1), a_rows=B * NP, a_row_group=NP, a_row_extra=1)
+            self._maybe_reduce(flat, "patch_embed.bias")
+            self._stem_backward(P, b, B, flat, dfeat)
+        else:
+            dpatch = dxs_bf.view(B, S, E)[:, 1:].contiguous().view(B, 14, 14, E)
+            dw = torch.zeros(E, 16 * 64, dtype=F32, device=dev)
+            ops.conv2d_wgrad(dpatch, b["img"], dw, kh=16, kw=1, stride=16, pad=0, seg_len=64)
+            g("patch_embed.weight").view(E, 16, 16, 3).copy_(dw.view(E, 16, 16, 4)[..., :3])
+            ops.colsum(dpatch.view(B * NP, E), g("patch_embed.bias"))
+        self._finish_reduce(flat)
+        return flat
+
+    # ---- bucketed all-reduce overlapped with backward ------------------------------------------------
+    def _maybe_reduce(self, flat, last_done_name: str) -> None:
+        if self.world_size <= 1:
+            return
+        off, n, _ = self.layout.offsets[last_done_name]
+        end = off + (n + 63) // 64 * 64
+        start = self._reduced_upto
+        if (end - start) * 4 >= self.bucket_bytes:
+            self._launch_reduce(flat, start, end)
+
+    def _launch_reduce(self, flat, start, end) -> None:
+        import torch.distributed as dist
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=flat.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        chunk = flat[start:end]
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(ev)
+            chunk.mul_(1.0 / self.world_size)
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.process_group)
+        chunk.record_stream(self._comm_stream)
+        self._reduced_upto = end
+
+    def _finish_reduce(self, flat) -> None:
+        if self.world_size <= 1:
+            return
+        start = self._reduced_upto
+        if start < self.layout.total:
+            self._launch_reduce(flat, start, self.layout.total)
+        torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._reduced_upto = 0
+
+    def grads_in_param_order(self, flat) -> List[torch.Tensor]:
+        out = []
+        m = self.m
+        for n in self.layout.param_order:
+            off, numel, shape = self.layout.offsets[n]
+            gseg = flat[off:off + numel]
+            if len(shape) == 4 and n.startswith("cnn_backbone.") and n != "cnn_backbone.conv1.weight":
+                co, ci, kh, kw = shape            # kernels write [Cout, kh, kw, Cin]
+                gseg = gseg.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            elif n == "cnn_backbone.conv1.weight":
+                gseg = gseg.view(64, 7, 7, 3).permute(0, 3, 1, 2)
+            elif n == "patch_embed.weight" and m.cnn_backbone is None:
+                gseg = gseg.view(shape[0], 16, 16, 3).permute(0, 3, 1, 2)
+            else:
+                gseg = gseg.view(shape)
+            out.append(gseg)
+        return out
+
+
+class HybridFunction(torch.autograd.Function):
+    """logits = f(x; params) with forward and backward on librvit."""
+
+    @staticmethod
+    def forward(ctx, x, eng: TrainEngine, features_only: bool, *params):
+        ctx.eng, ctx.features_only, ctx.B = eng, features_only, x.shape[0]
+        return eng.forward(x, features_only)
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.eng
+        flat = eng.backward(dout.contiguous().float(), ctx.features_only, ctx.B)
+        return (None, None, None, *eng.grads_in_param_order(flat))
