@@ -84,20 +84,12 @@ class TrainEngine:
         self._pack = None
         self._pack_key = None
         self._bufs: Dict[int, dict] = {}
-        self.process_group = None
-        self.world_size = 1
-        self.bucket_bytes = 25 << 20
-        self._comm_stream = None
-        self._reduced_upto = 0
+        self.reducer = None
 
     # ---- data parallel -------------------------------------------------------------------------
     def set_data_parallel(self, process_group=None, bucket_mb: float = 25.0) -> None:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised")
-        self.process_group = process_group if process_group is not None else dist.group.WORLD
-        self.world_size = dist.get_world_size(self.process_group)
-        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        from .dp import BucketReducer
+        self.reducer = BucketReducer(self.layout.total, process_group, int(bucket_mb * (1 << 20)))
 
     # ---- packing ---------------------------------------------------------------------------------
     def _key(self):
@@ -381,6 +373,8 @@ class TrainEngine:
         T = B * S
         L = self.layout
         flat = torch.zeros(L.total, dtype=F32, device=dev)
+        if self.reducer is not None:
+            self.reducer.begin_step()
         g, g2 = lambda n: self._g(flat, n), lambda n, r: self._g2(flat, n, r)  # noqa: E731
         dxs, dxs_bf = b["dxs"], b["dxs_bf"]
         dxs.zero_()
@@ -455,36 +449,15 @@ class TrainEngine:
 
     # ---- bucketed all-reduce overlapped with backward ------------------------------------------------
     def _maybe_reduce(self, flat, last_done_name: str) -> None:
-        if self.world_size <= 1:
+        """Everything up to and including `last_done_name` (layout order) is final."""
+        if self.reducer is None:
             return
         off, n, _ = self.layout.offsets[last_done_name]
-        end = off + (n + 63) // 64 * 64
-        start = self._reduced_upto
-        if (end - start) * 4 >= self.bucket_bytes:
-            self._launch_reduce(flat, start, end)
-
-    def _launch_reduce(self, flat, start, end) -> None:
-        import torch.distributed as dist
-        if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(device=flat.device)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        chunk = flat[start:end]
-        with torch.cuda.stream(self._comm_stream):
-            self._comm_stream.wait_event(ev)
-            chunk.mul_(1.0 / self.world_size)
-            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.process_group)
-        chunk.record_stream(self._comm_stream)
-        self._reduced_upto = end
+        self.reducer.ready(flat, off + (n + 63) // 64 * 64)
 
     def _finish_reduce(self, flat) -> None:
-        if self.world_size <= 1:
-            return
-        start = self._reduced_upto
-        if start < self.layout.total:
-            self._launch_reduce(flat, start, self.layout.total)
-        torch.cuda.current_stream().wait_stream(self._comm_stream)
-        self._reduced_upto = 0
+        if self.reducer is not None:
+            self.reducer.finish(flat)
 
     def grads_in_param_order(self, flat) -> List[torch.Tensor]:
         out = []
