@@ -53,6 +53,75 @@ def cpu_baseline(sd, seconds=20.0, batch=8):
                       f"same weights/inputs generator"}
 
 
+def train_leg(args, dev, dist, world, rank, sd):
+    """Secondary figure (BASELINE.json configs[3] shape on the R model): one optimiser step =
+    forward in train() mode (BatchNorm batch statistics) + label-smoothed CE + backward on librvit +
+    bucketed gradient all-reduce (N>1, overlapped with backward) + grad-norm clipping + AdamW
+    (train_vit.py:407-437).  Same timing discipline as the headline number."""
+    from vit_amd import ops
+    from vit_amd.loss import CrossEntropyLoss
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.synth import micro_doppler_batch
+    cfg = dict(R_CFG, dropout=args.train_dropout)
+    model = CNNViTHybrid(**cfg)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    if world > 1:
+        model.set_data_parallel()
+    B = args.train_batch
+    x = torch.cat([micro_doppler_batch(min(64, B - i), seed=99 + 1000 * rank + i) for i in range(0, B, 64)]).to(dev)
+    y = torch.randint(0, cfg["num_classes"], (B,), generator=torch.Generator().manual_seed(rank)).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    crit = CrossEntropyLoss(label_smoothing=0.05)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(model(x), y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(3):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kernels = {}
+    if rank == 0 or dist is not None:  # every rank must run the same collectives
+        rec = []
+        ops.set_profiler(rec)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        ops.set_profiler(None)
+        for name, e0, e1, fl, nb in rec:
+            kernels[name] = kernels.get(name, 0.0) + e0.elapsed_time(e1) / 2
+    if rank != 0:
+        return None
+    sps = world * B * args.train_steps / dt
+    return {"metric": "train_samples_per_sec", "value": round(sps, 1), "unit": "samples/s",
+            "ms_per_step": round(dt / args.train_steps * 1e3, 3), "steps": args.train_steps, "batch_per_gpu": B,
+            "global_batch": world * B, "dropout": cfg["dropout"], "final_loss": round(float(loss), 4),
+            "includes": "forward(train-mode BN) + CE(label_smoothing=0.05) + backward + "
+                        + ("bucketed RCCL all-reduce + " if world > 1 else "") + "clip_grad_norm + fused AdamW",
+            "model_tflops": round(sps * 3 * FWD_FLOPS_PER_SAMPLE / 1e12, 2),
+            "kernel_ms_per_step": {n: round(v, 4) for n, v in sorted(kernels.items())}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +129,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=256, help="samples per GPU per training step")
+    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--train-dropout", type=float, default=0.0)
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +210,11 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": k["launches"] // min(args.steps, 5)}
 
+    train = None
+    if not args.no_train:
+        del x
+        train = train_leg(args, dev, dist, world, rank, sd)
+
     if rank == 0:
         frames = world * B * args.steps
         value = frames / dt
@@ -152,6 +230,8 @@ def main():
             "roofline": roofline,
             "kernel_ms_per_step": {n: round(v["ms"] / min(args.steps, 5), 4) for n, v in sorted(kernels.items())},
         }
+        if train is not None:
+            out["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)

@@ -49,3 +49,25 @@ for name, M, N, K in gemms:
     for tile in tiles:
         us = timeit(lambda: ops.gemm(a, w, o, bias=bi, tile=tile))
         print(f"{name:18s} tile={tile} {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TF/s  {(M*K+N*K+M*N)*2/us/1e3:8.1f} GB/s(alg)")
+
+if os.environ.get("RVIT_BENCH_BWD", "1") == "1":
+    print("---- backward: dgrad / wgrad per shape ----")
+    for name, H, W, cin, cout, kh, kw, s, p, seg, ho in convs:
+        dy = torch.randn(B, ho, ho, cout, device=dev).to(bf)
+        x = torch.randn(B, H, W, cin, device=dev).to(bf)
+        seg_len = cin if seg is None else seg
+        dw = torch.zeros(cout, kh * kw * seg_len, device=dev)
+        fl = 2.0 * B * ho * ho * cout * kh * kw * seg_len
+        us = timeit(lambda: ops.conv2d_wgrad(dy, x, dw, kh=kh, kw=kw, stride=s, pad=p, seg_len=seg))
+        print(f"wgrad {name:18s} {us:9.1f} us  {fl/us/1e6:8.1f} TF/s  {(dy.numel()+x.numel())*2/us/1e3:8.1f} GB/s(alg)")
+        if seg is None:
+            w_t = (torch.randn(cin, kh * kw * cout, device=dev) * 0.05).to(bf)
+            dx = torch.empty(B, H, W, cin, device=dev, dtype=bf)
+            for tile in tiles:
+                us = timeit(lambda: ops.conv2d_dgrad(dy, w_t, dx, kh=kh, kw=kw, stride=s, pad=p, tile=tile))
+                print(f"dgrad {name:18s} tile={tile} {us:9.1f} us  {fl/us/1e6:8.1f} TF/s  {(dy.numel()+dx.numel())*2/us/1e3:8.1f} GB/s(alg)")
+    for name, M, N, K in gemms[:5]:
+        dy = torch.randn(M, N, device=dev).to(bf); x = torch.randn(M, K, device=dev).to(bf)
+        dw = torch.zeros(N, K, device=dev)
+        us = timeit(lambda: ops.wgrad(dy, x, dw))
+        print(f"wgrad {name:18s} {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TF/s  {(M*K+M*N)*2/us/1e3:8.1f} GB/s(alg)")

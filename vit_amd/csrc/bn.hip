@@ -27,10 +27,10 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 
 // grid-stride row partition shared by the reduction kernels
 struct RowSpan { long m0, m1; int chunk, r, rows_per_pass; };
-__device__ __forceinline__ RowSpan row_span(long M, int C) {
+__device__ __forceinline__ RowSpan row_span(long M, int C, int threads = 256) {
   RowSpan s;
   const int cpr = C >> 3;
-  s.rows_per_pass = 256 / cpr;
+  s.rows_per_pass = threads / cpr;
   s.chunk = threadIdx.x % cpr;
   s.r = threadIdx.x / cpr;
   const long per = (M + gridDim.x - 1) / gridDim.x;
@@ -39,29 +39,65 @@ __device__ __forceinline__ RowSpan row_span(long M, int C) {
   return s;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ y, long M, int C,
-                                                       float* __restrict__ sums) {
+// Every kernel below gives a thread one fixed 8-channel chunk and a strided set of rows of the
+// workgroup's contiguous row range: the per-channel constants are derived once per thread, a pass of
+// the workgroup touches 4 KB of contiguous memory, and UNROLL rows are in flight per thread.
+// The two reduction kernels run 1024 threads per workgroup and at most one workgroup per CU: all
+// per-channel totals live in a few cache lines of one L2 channel, whose atomic rate (a few per clock)
+// would otherwise dominate.  Lanes of a wave that share a channel chunk combine by shuffles first.
+constexpr int RED_THREADS = 1024;
+
+__device__ __forceinline__ void red_commit(float* red, int C, int chunk, float (&a)[8], float (&b)[8]) {
+  const int cpr = C >> 3, lane = threadIdx.x & 63;
+  for (int off = 32; off >= cpr; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a[k] += __shfl_xor(a[k], off, 64);
+      b[k] += __shfl_xor(b[k], off, 64);
+    }
+  }
+  if (cpr >= 64 || lane < cpr) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      atomicAdd(&red[chunk * 8 + k], a[k]);
+      atomicAdd(&red[C + chunk * 8 + k], b[k]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const bf16* __restrict__ y, long M, int C,
+                                                               float* __restrict__ sums) {
   extern __shared__ float red[];  // [2*C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) red[i] = 0.f;
   __syncthreads();
-  const RowSpan s = row_span(M, C);
+  const RowSpan s = row_span(M, C, RED_THREADS);
+  const long step = s.rows_per_pass;
+  const bf16* base = y + s.chunk * 8;
   float a[8], q[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { a[k] = 0.f; q[k] = 0.f; }
-  if (s.r < s.rows_per_pass)
-    for (long m = s.m0 + s.r; m < s.m1; m += s.rows_per_pass) {
+  long m = s.m0 + s.r;
+  for (; m + 3 * step < s.m1; m += 4 * step) {
+    uint4 u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const uint4*>(base + (m + j * step) * C);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
       float v[8];
-      unpack8(*reinterpret_cast<const uint4*>(y + m * C + s.chunk * 8), v);
+      unpack8(u[j], v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) { a[k] += v[k]; q[k] += v[k] * v[k]; }
     }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    atomicAdd(&red[s.chunk * 8 + k], a[k]);
-    atomicAdd(&red[C + s.chunk * 8 + k], q[k]);
   }
+  for (; m < s.m1; m += step) {
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(base + m * C), v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] += v[k]; q[k] += v[k] * v[k]; }
+  }
+  red_commit(red, C, s.chunk, a, q);
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(sums + i, red[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) atomicAdd(sums + i, red[i]);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ y, const float* __restrict__ sums,
@@ -70,11 +106,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
                                                        float eps, int relu, float momentum,
                                                        float* __restrict__ running_mean,
                                                        float* __restrict__ running_var) {
-  const int cpr = C >> 3;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long m = idx / cpr;
-  const int c0 = (int)(idx - m * cpr) * 8;
-  if (m >= M) return;
+  const RowSpan s = row_span(M, C);
+  const long step = s.rows_per_pass;
+  const int c0 = s.chunk * 8;
   const float inv_m = 1.0f / (float)M;
   float sc[8], sh[8];
 #pragma unroll
@@ -84,72 +118,123 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
     const float rstd = 1.0f / sqrtf(var + eps);
     sc[k] = gamma[c0 + k] * rstd;
     sh[k] = beta[c0 + k] - mean * sc[k];
-    if (m == 0 && running_mean) {  // exactly one thread per channel: row 0
+    if (blockIdx.x == 0 && s.r == 0 && running_mean) {  // exactly one thread per channel
       const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
       running_mean[c0 + k] = (1.f - momentum) * running_mean[c0 + k] + momentum * mean;
       running_var[c0 + k] = (1.f - momentum) * running_var[c0 + k] + momentum * unbiased;
     }
   }
-  float v[8];
-  unpack8(*reinterpret_cast<const uint4*>(y + m * C + c0), v);
+  const float lo = relu ? 0.f : -INFINITY;
+  long m = s.m0 + s.r;
+  for (; m + 3 * step < s.m1; m += 4 * step) {
+    uint4 u[4], r4[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sh[k];
-  if (res) {
-    float r[8];
-    unpack8(*reinterpret_cast<const uint4*>(res + m * C + c0), r);
+    for (int j = 0; j < 4; ++j) {
+      const long o = (m + j * step) * C + c0;
+      u[j] = *reinterpret_cast<const uint4*>(y + o);
+      if (res) r4[j] = *reinterpret_cast<const uint4*>(res + o);
+    }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] += r[k];
+    for (int j = 0; j < 4; ++j) {
+      float v[8];
+      unpack8(u[j], v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sh[k];
+      if (res) {
+        float r[8];
+        unpack8(r4[j], r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += r[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], lo);
+      *reinterpret_cast<uint4*>(z + (m + j * step) * C + c0) = pack8(v);
+    }
   }
-  if (relu) {
+  for (; m < s.m1; m += step) {
+    const long o = m * C + c0;
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4*>(y + o), v);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sh[k];
+    if (res) {
+      float r[8];
+      unpack8(*reinterpret_cast<const uint4*>(res + o), r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], lo);
+    *reinterpret_cast<uint4*>(z + o) = pack8(v);
   }
-  *reinterpret_cast<uint4*>(z + m * C + c0) = pack8(v);
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ z,
-                                                            const bf16* __restrict__ y, const float* __restrict__ fsums,
-                                                            long M, int C, float eps, int relu,
-                                                            float* __restrict__ bsums) {
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* __restrict__ dz,
+                                                                    const bf16* __restrict__ z,
+                                                                    const bf16* __restrict__ y,
+                                                                    const float* __restrict__ fsums, long M, int C,
+                                                                    float eps, int relu, float* __restrict__ bsums) {
   extern __shared__ float red[];  // [2*C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) red[i] = 0.f;
   __syncthreads();
-  const RowSpan s = row_span(M, C);
+  const RowSpan s = row_span(M, C, RED_THREADS);
+  const long step = s.rows_per_pass;
+  const int c0 = s.chunk * 8;
   const float inv_m = 1.0f / (float)M;
-  float mean[8], rstd[8], s1[8], s2[8];
+  float mean[8], s1[8], s2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int c = s.chunk * 8 + k;
-    mean[k] = fsums[c] * inv_m;
-    const float var = fmaxf(fsums[C + c] * inv_m - mean[k] * mean[k], 0.f);
-    rstd[k] = 1.0f / sqrtf(var + eps);
+    mean[k] = fsums[c0 + k] * inv_m;
     s1[k] = 0.f; s2[k] = 0.f;
   }
-  if (s.r < s.rows_per_pass)
-    for (long m = s.m0 + s.r; m < s.m1; m += s.rows_per_pass) {
-      const long o = m * C + s.chunk * 8;
+  // s2 accumulates sum dzm*(y-mean); rstd is applied once at the end
+  long m = s.m0 + s.r;
+  for (; m + step < s.m1; m += 2 * step) {
+    uint4 du[2], yu[2], zu[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long o = (m + j * step) * C + c0;
+      du[j] = *reinterpret_cast<const uint4*>(dz + o);
+      yu[j] = *reinterpret_cast<const uint4*>(y + o);
+      if (relu) zu[j] = *reinterpret_cast<const uint4*>(z + o);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
       float d[8], yv[8];
-      unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
-      unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
+      unpack8(du[j], d);
+      unpack8(yu[j], yv);
       if (relu) {
         float zv[8];
-        unpack8(*reinterpret_cast<const uint4*>(z + o), zv);
+        unpack8(zu[j], zv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        s1[k] += d[k];
-        s2[k] += d[k] * (yv[k] - mean[k]) * rstd[k];
-      }
+      for (int k = 0; k < 8; ++k) { s1[k] += d[k]; s2[k] += d[k] * (yv[k] - mean[k]); }
+    }
+  }
+  for (; m < s.m1; m += step) {
+    const long o = m * C + c0;
+    float d[8], yv[8];
+    unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
+    unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
+    if (relu) {
+      float zv[8];
+      unpack8(*reinterpret_cast<const uint4*>(z + o), zv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
     }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    atomicAdd(&red[s.chunk * 8 + k], s1[k]);
-    atomicAdd(&red[C + s.chunk * 8 + k], s2[k]);
+    for (int k = 0; k < 8; ++k) { s1[k] += d[k]; s2[k] += d[k] * (yv[k] - mean[k]); }
   }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float var = fmaxf(fsums[C + c0 + k] * inv_m - mean[k] * mean[k], 0.f);
+    s2[k] *= 1.0f / sqrtf(var + eps);
+  }
+  red_commit(red, C, s.chunk, s1, s2);
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(bsums + i, red[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) atomicAdd(bsums + i, red[i]);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ z,
@@ -159,39 +244,71 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
                                                            bf16* __restrict__ dzm_out, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, long M, int C, float eps,
                                                            int relu) {
-  const int cpr = C >> 3;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const long m = idx / cpr;
-  const int c0 = (int)(idx - m * cpr) * 8;
-  if (m >= M) return;
+  const RowSpan s = row_span(M, C);
+  const long step = s.rows_per_pass;
+  const int c0 = s.chunk * 8;
   const float inv_m = 1.0f / (float)M;
-  const long o = m * C + c0;
-  float d[8], yv[8];
-  unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
-  unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
-  if (relu) {
-    float zv[8];
-    unpack8(*reinterpret_cast<const uint4*>(z + o), zv);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
-  }
-  if (dzm_out) *reinterpret_cast<uint4*>(dzm_out + o) = pack8(d);
-  float out[8];
+  // dy = a*dzm + b*y + c  with a = gamma*rstd, b = -a*rstd*bs2/M, c = -a*bs1/M - b*mean
+  float ca[8], cb[8], cc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = c0 + k;
     const float mean = fsums[c] * inv_m;
     const float var = fmaxf(fsums[C + c] * inv_m - mean * mean, 0.f);
     const float rstd = 1.0f / sqrtf(var + eps);
-    const float xhat = (yv[k] - mean) * rstd;
     const float b1 = bsums[c], b2 = bsums[C + c];
-    out[k] = gamma[c] * rstd * (d[k] - b1 * inv_m - xhat * b2 * inv_m);
-    if (m == 0) {  // one thread per channel
+    ca[k] = gamma[c] * rstd;
+    cb[k] = -ca[k] * rstd * b2 * inv_m;
+    cc[k] = -ca[k] * b1 * inv_m - cb[k] * mean;
+    if (blockIdx.x == 0 && s.r == 0) {  // one thread per channel
       dgamma[c] += b2;
       dbeta[c] += b1;
     }
   }
-  *reinterpret_cast<uint4*>(dy + o) = pack8(out);
+  long m = s.m0 + s.r;
+  for (; m + step < s.m1; m += 2 * step) {
+    uint4 du[2], yu[2], zu[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long o = (m + j * step) * C + c0;
+      du[j] = *reinterpret_cast<const uint4*>(dz + o);
+      yu[j] = *reinterpret_cast<const uint4*>(y + o);
+      if (relu) zu[j] = *reinterpret_cast<const uint4*>(z + o);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long o = (m + j * step) * C + c0;
+      float d[8], yv[8], out[8];
+      unpack8(du[j], d);
+      unpack8(yu[j], yv);
+      if (relu) {
+        float zv[8];
+        unpack8(zu[j], zv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
+      }
+      if (dzm_out) *reinterpret_cast<uint4*>(dzm_out + o) = pack8(d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) out[k] = ca[k] * d[k] + cb[k] * yv[k] + cc[k];
+      *reinterpret_cast<uint4*>(dy + o) = pack8(out);
+    }
+  }
+  for (; m < s.m1; m += step) {
+    const long o = m * C + c0;
+    float d[8], yv[8], out[8];
+    unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
+    unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
+    if (relu) {
+      float zv[8];
+      unpack8(*reinterpret_cast<const uint4*>(z + o), zv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
+    }
+    if (dzm_out) *reinterpret_cast<uint4*>(dzm_out + o) = pack8(d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[k] = ca[k] * d[k] + cb[k] * yv[k] + cc[k];
+    *reinterpret_cast<uint4*>(dy + o) = pack8(out);
+  }
 }
 
 // dx[b,hi,wi,c] = sum over the (<= 4) 3x3/2 windows containing (hi,wi) whose recorded argmax tap
@@ -235,16 +352,27 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* __restrict
   *reinterpret_cast<uint4*>(dx + (((long)b * H + hi) * W + wi) * C + cq * 8) = pack8(acc);
 }
 
-bool bn_shape_ok(long M, int C) { return M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (256 % (C >> 3)) == 0; }
+bool bn_shape_ok(long M, int C) { return M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (256 % (C >> 3)) == 0; }  // C/8 a power of two <= 256
+
+// workgroups for M rows when a thread should see about `rows_per_thread` rows; 8 workgroups per CU at most
+long bn_blocks(long M, int C, int rows_per_thread) {
+  const long per = (long)(256 / (C >> 3)) * rows_per_thread;
+  long blocks = (M + per - 1) / per;
+  return blocks > 2048 ? 2048 : blocks;
+}
+
+long red_blocks(long M, int C) {
+  const long per = (long)(RED_THREADS / (C >> 3)) * 4;
+  long blocks = (M + per - 1) / per;
+  return blocks > 256 ? 256 : blocks;
+}
 
 }  // namespace
 
 int rvit_bn_stats_impl(const void* y, long M, int C, float* sums, hipStream_t st) {
   RVIT_CHECK_ARG(y && sums && bn_shape_ok(M, C) && rvit_aligned16(y), "bn_stats: bad arguments (M=%ld C=%d)", M, C);
-  const int rows_per_pass = 256 / (C >> 3);
-  long blocks = (M + rows_per_pass * 8 - 1) / (rows_per_pass * 8);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float), st, (const bf16*)y, M, C,
+  const long blocks = red_blocks(M, C);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), 2 * C * sizeof(float), st, (const bf16*)y, M, C,
                      sums);
   RVIT_CHECK_LAUNCH("bn_stats");
   return RVIT_OK;
@@ -256,8 +384,8 @@ int rvit_bn_apply_impl(const void* y, const float* sums, const float* gamma, con
   RVIT_CHECK_ARG(y && sums && gamma && beta && z && bn_shape_ok(M, C), "bn_apply: bad arguments");
   RVIT_CHECK_ARG(rvit_aligned16(y) && rvit_aligned16(z) && (!res || rvit_aligned16(res)), "bn_apply: alignment");
   RVIT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_apply: running stats come in pairs");
-  const long total = M * (C >> 3);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16*)y, sums,
+  const long blocks = bn_blocks(M, C, 8);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)y, sums,
                      gamma, beta, (const bf16*)res, (bf16*)z, M, C, eps, relu, momentum, running_mean, running_var);
   RVIT_CHECK_LAUNCH("bn_apply");
   return RVIT_OK;
@@ -267,10 +395,8 @@ int rvit_bn_bwd_reduce_impl(const void* dz, const void* z, const void* y, const 
                             int relu, float* bsums, hipStream_t st) {
   RVIT_CHECK_ARG(dz && y && fsums && bsums && (!relu || z) && bn_shape_ok(M, C), "bn_bwd_reduce: bad arguments");
   RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && (!z || rvit_aligned16(z)), "bn_bwd_reduce: alignment");
-  const int rows_per_pass = 256 / (C >> 3);
-  long blocks = (M + rows_per_pass * 8 - 1) / (rows_per_pass * 8);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float), st,
+  const long blocks = red_blocks(M, C);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), 2 * C * sizeof(float), st,
                      (const bf16*)dz, (const bf16*)z, (const bf16*)y, fsums, M, C, eps, relu, bsums);
   RVIT_CHECK_LAUNCH("bn_bwd_reduce");
   return RVIT_OK;
@@ -284,8 +410,8 @@ int rvit_bn_bwd_apply_impl(const void* dz, const void* z, const void* y, const f
   RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && rvit_aligned16(dy) && (!z || rvit_aligned16(z)) &&
                      (!dzm_out || rvit_aligned16(dzm_out)),
                  "bn_bwd_apply: alignment");
-  const long total = M * (C >> 3);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16*)dz,
+  const long blocks = bn_blocks(M, C, 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dz,
                      (const bf16*)z, (const bf16*)y, fsums, bsums, gamma, (bf16*)dy, (bf16*)dzm_out, dgamma, dbeta, M,
                      C, eps, relu);
   RVIT_CHECK_LAUNCH("bn_bwd_apply");

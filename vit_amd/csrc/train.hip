@@ -9,12 +9,13 @@ namespace {
 // LayerNorm backward, fused with the residual-gradient accumulation of the pre-LN block:
 //   dxs[row] (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // and an optional bf16 copy of the updated residual gradient (A operand of the next dgrad/wgrad).
-// dgamma / dbeta are reduced per wave in registers over a grid-stride row loop and added with
-// one atomic per column per wave.
+// dgamma / dbeta are reduced per wave in registers over a grid-stride row loop, then across the
+// waves of the workgroup in LDS, and added with one global atomic per column per workgroup (at most
+// 256 workgroups: same-address atomics serialise in L2, 2M of them cost more than the whole pass).
 constexpr int LNB_MAX_IT = 8;
 
-template <int IT>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restrict__ dy, long lddy,
+template <int IT, int THREADS>
+__global__ __launch_bounds__(THREADS) void layernorm_bwd_kernel(const bf16* __restrict__ dy, long lddy,
                                                             const float* __restrict__ x, long ldx,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -22,9 +23,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
                                                             long lddx, int accumulate, bf16* __restrict__ dx_bf16,
                                                             long lddb, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, long rows, int E) {
+  extern __shared__ float lnb_red[];  // [2 * IT * 256]
+  constexpr int WAVES = THREADS / 64;
   const int lane = threadIdx.x & 63;
-  const long wave_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long nwaves = (long)gridDim.x * 4;
+  const long wave_id = (long)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * WAVES;
+  for (int i = threadIdx.x; i < 2 * IT * 256; i += THREADS) lnb_red[i] = 0.f;
+  __syncthreads();
   float gam[IT][4], dg[IT][4], db[IT][4];
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
@@ -88,13 +93,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16* __restri
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int e = it * 256 + lane * 4;
-    if (e < E) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        atomicAdd(dgamma + e + k, dg[it][k]);
-        atomicAdd(dbeta + e + k, db[it][k]);
-      }
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&lnb_red[e + k], dg[it][k]);
+      atomicAdd(&lnb_red[IT * 256 + e + k], db[it][k]);
     }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += THREADS) {
+    atomicAdd(dgamma + e, lnb_red[e]);
+    atomicAdd(dbeta + e, lnb_red[IT * 256 + e]);
   }
 }
 
@@ -132,28 +140,61 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // Column sums of a bf16 matrix into fp32 (bias gradients): out[n] += sum_m A[m,n].
+// A workgroup covers 256 columns (32 lanes x 16 B) x 8 row lanes, four rows in flight per thread;
+// partial sums meet in LDS and leave with one atomic per column per workgroup.
+__device__ __forceinline__ long colsum_row(long m, long row_group, long row_extra) {
+  if (row_group <= 0) return m;
+  const long g = m / row_group;
+  return g * (row_group + row_extra) + (m - g * row_group) + row_extra;
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ a, long lda, float* __restrict__ out,
                                                      long M, int N, long row_group, long row_extra) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + tx;
+  __shared__ float red[256];
+  red[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n0 = blockIdx.x * 256 + tx * 8;
   const long per = (M + gridDim.y - 1) / gridDim.y;
   const long m0 = (long)blockIdx.y * per;
   long m1 = m0 + per;
   if (m1 > M) m1 = M;
-  float s = 0.f;
-  if (n < N)
-    for (long m = m0 + ty; m < m1; m += 4) {
-      long r = m;
-      if (row_group > 0) {
-        const long g = m / row_group;
-        r = g * (row_group + row_extra) + (m - g * row_group) + row_extra;
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  if (n0 < N) {
+    if (n0 + 8 <= N && (lda & 7) == 0) {
+      long m = m0 + ty;
+      for (; m + 24 < m1; m += 32) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[u] = *reinterpret_cast<const uint4*>(a + colsum_row(m + 8 * u, row_group, row_extra) * lda + n0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s[0] += bf16_lo(v[u].x); s[1] += bf16_hi(v[u].x); s[2] += bf16_lo(v[u].y); s[3] += bf16_hi(v[u].y);
+          s[4] += bf16_lo(v[u].z); s[5] += bf16_hi(v[u].z); s[6] += bf16_lo(v[u].w); s[7] += bf16_hi(v[u].w);
+        }
       }
-      s += (float)a[r * lda + n];
+      for (; m < m1; m += 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a + colsum_row(m, row_group, row_extra) * lda + n0);
+        s[0] += bf16_lo(v.x); s[1] += bf16_hi(v.x); s[2] += bf16_lo(v.y); s[3] += bf16_hi(v.y);
+        s[4] += bf16_lo(v.z); s[5] += bf16_hi(v.z); s[6] += bf16_lo(v.w); s[7] += bf16_hi(v.w);
+      }
+    } else {  // ragged tail columns or unaligned pitch
+      for (long m = m0 + ty; m < m1; m += 8) {
+        const bf16* row = a + colsum_row(m, row_group, row_extra) * lda;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (n0 + k < N) s[k] += (float)row[n0 + k];
+      }
     }
-  red[ty][tx] = s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&red[tx * 8 + k], s[k]);
+  }
   __syncthreads();
-  if (ty == 0 && n < N) atomicAdd(out + n, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) atomicAdd(out + n, red[threadIdx.x]);
 }
 
 // out[j] += sum_b x[b, j]  (pos_embed / cls_token gradients: sum of the token gradients over the batch)
@@ -184,17 +225,20 @@ int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx,
                      ((uintptr_t)dx_bf16 & 7) == 0,
                  "layernorm_bwd: alignment");
   if (rows <= 0) return RVIT_OK;
-  long blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
   const int it = (E + 255) / 256;
-#define LNB_CASE(N)                                                                                             \
+  // 16 waves per workgroup while the per-lane state fits 128 VGPRs, 4 beyond; one workgroup per CU at most
+  const int threads = it <= 3 ? 1024 : 256;
+  long blocks = (rows + threads / 64 - 1) / (threads / 64);
+  if (blocks > 256) blocks = 256;
+#define LNB_CASE(N, T)                                                                                          \
   case N:                                                                                                       \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<N>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dy,    \
-                       lddy, x, ldx, mean, rstd, gamma, dxs, lddx, accumulate, (bf16*)dx_bf16, lddb, dgamma,    \
-                       dbeta, rows, E);                                                                         \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<N, T>), dim3((unsigned)blocks), dim3(T), 2 * N * 256 * sizeof(float), \
+                       st, (const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dxs, lddx, accumulate,             \
+                       (bf16*)dx_bf16, lddb, dgamma, dbeta, rows, E);                                           \
     break;
   switch (it) {
-    LNB_CASE(1) LNB_CASE(2) LNB_CASE(3) LNB_CASE(4) LNB_CASE(5) LNB_CASE(6) LNB_CASE(7) LNB_CASE(8)
+    LNB_CASE(1, 1024) LNB_CASE(2, 1024) LNB_CASE(3, 1024) LNB_CASE(4, 256) LNB_CASE(5, 256) LNB_CASE(6, 256)
+    LNB_CASE(7, 256) LNB_CASE(8, 256)
     default: rvit_set_error("layernorm_bwd: E=%d unsupported", E); return RVIT_EUNSUPPORTED;
   }
 #undef LNB_CASE
@@ -217,9 +261,12 @@ int rvit_colsum_impl(const void* a, long lda, float* out, long M, int N, long ro
                      hipStream_t st) {
   RVIT_CHECK_ARG(a && out && M >= 0 && N > 0 && lda >= N, "colsum: bad arguments");
   if (M == 0) return RVIT_OK;
-  long ysplit = (M + 255) / 256;
-  if (ysplit > 256) ysplit = 256;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)ysplit), dim3(256), 0, st,
+  RVIT_CHECK_ARG(((uintptr_t)a & 15) == 0 || (lda & 7) != 0, "colsum: a must be 16-byte aligned");
+  const int xb = (N + 255) / 256;
+  long ysplit = (M + 63) / 64;
+  const long cap = (256 + xb - 1) / xb;  // few workgroups: the column totals share one L2 channel's atomic unit
+  if (ysplit > cap) ysplit = cap;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)xb, (unsigned)ysplit), dim3(256), 0, st,
                      (const bf16*)a, lda, out, M, N, row_group, row_extra);
   RVIT_CHECK_LAUNCH("colsum");
   return RVIT_OK;
