@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-batch", type=int, default=256, help="samples per GPU per training step")
     ap.add_argument("--train-steps", type=int, default=8)
-    ap.add_argument("--train-dropout", type=float, default=0.0)
+    ap.add_argument("--train-dropout", type=float, default=0.1)
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput leg")
     args = ap.parse_args()
 

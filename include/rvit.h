@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 2
+#define RVIT_ABI_VERSION 3
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -35,6 +35,18 @@ extern "C" {
 
 #define RVIT_GATE_GELU_GRAD 1 /* value *= gelu'(gate)   (backward of nn.GELU) */
 #define RVIT_GATE_RELU_MASK 2 /* value *= (gate > 0)    (backward of ReLU)    */
+
+/* Dropout (nn.Dropout(p) at train_vit.py:100,107,125 = pos_drop, the encoder layers' dropout /
+ * dropout1 / dropout2 and the head's; attention-probability dropout, torch functional.py:6569-6570).
+ * A site is keyed by (drop_p, drop_seed); element idx is kept iff the top 24 bits of
+ * mix32(mix32(idx + lo32(seed)) ^ hi32(seed)) >= round(p * 2^24), kept values are scaled by 1/(1-p)
+ * (mix32 = the "lowbias32" integer hash, csrc/common.h).  Nothing is stored: the backward entry
+ * points regenerate the decision from the same (p, seed).  torch's Philox stream is NOT reproduced
+ * (no kernel can): the distribution matches, the individual masks do not.
+ * drop_p == 0 disables.  Position of the dropout in a GEMM epilogue: */
+#define RVIT_DROP_PRE_RESIDUAL 1 /* C = act(drop(scale*acc + bias) + R): dropout1 / dropout2 */
+#define RVIT_DROP_POST_ACT 2     /* C = drop(act(... + R)): FFN / head dropout, pos_drop; also the mask multiply of
+                                    the matching backward GEMM (after `gate`)                     */
 
 #define RVIT_OK 0
 #define RVIT_EINVAL (-1)
@@ -56,12 +68,13 @@ const char* rvit_last_error(void);
  *   gate: optional bf16 [.,ldg] indexed like C, gate_mode RVIT_GATE_*
  *   R: optional residual (bf16 or f32), row = m % r_period when r_period > 0, else the C row
  *   row remap (row_group, row_extra) applies to C, preact, gate and R
+ *   drop_mode / drop_p / drop_seed: dropout in the epilogue (above); element index = C row * N + column
  *   tile: 0 = automatic tile choice, 1/2/3 force 256x64 / 128x64 / 64x64 (testing). */
 int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int c_dtype, int64_t M, int N, int K, const float* scale, const float* bias,
                    const void* gate, int64_t ldg, int gate_mode, const void* R, int64_t ldr, int r_dtype,
-                   int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra, int tile,
-                   void* stream);
+                   int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra, int drop_mode,
+                   float drop_p, uint64_t drop_seed, int tile, void* stream);
 
 /* NHWC implicit-GEMM convolution, bf16 MFMA: y = act( scale[c]*conv(x, w) + bias[c] + residual ).
  * Replaces the timm resnet18 feature extractor convs + (eval-mode, folded) BatchNorm + ReLU +
@@ -85,10 +98,11 @@ int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int
 /* Patch-embedding convolution straight into the token stream (pure-ViT `patch16` layout; the
  * same flatten/transpose/cls-offset/pos_embed epilogue as the 1x1 case, train_vit.py:149-159):
  * tokens[b, 1+p, :] = conv(x, w)[b, p, :] + bias + pos_embed[1+p, :], fp32 [B, Ho*Wo+1, Cout].
- * Row 0 of every sample (cls) is left untouched (rvit_embed_cls writes it). */
+ * Row 0 of every sample (cls) is left untouched (rvit_embed_cls writes it).  drop_p > 0 applies
+ * pos_drop (train_vit.py:160) with element index = token row * Cout + column. */
 int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* bias,
-                           const float* pos_embed, int tile, void* stream);
+                           const float* pos_embed, float drop_p, uint64_t drop_seed, int tile, void* stream);
 
 /* Weight gradient of a Linear: dW[N_store,K] += dY[M,N]^T . X[M,K] (fp32 atomics, accumulates like
  * autograd's .grad).  dY: bf16 [.,ldy], X: bf16 [.,ldx], optional row remaps; N, K, ldy, ldx
@@ -113,8 +127,20 @@ int rvit_input_pack_nhwc4(const float* x_nchw, void* out, int B, int C, int H, i
  * argmax (optional, uint8 same shape as y) records the winning tap for the backward pass. */
 int rvit_maxpool3x3s2_nhwc(const void* x, void* y, void* argmax, int B, int H, int W, int C, void* stream);
 
-/* x[b,0,:] = cls_token + pos_embed[0] on the fp32 residual stream [B,S,E] (train_vit.py:155-159). */
-int rvit_embed_cls(const float* cls_token, const float* pos_embed, float* x, int B, int S, int E, void* stream);
+/* x[b,0,:] = drop(cls_token + pos_embed[0]) on the fp32 residual stream [B,S,E]
+ * (train_vit.py:155-160); same dropout site and element indexing as the patch rows. */
+int rvit_embed_cls(const float* cls_token, const float* pos_embed, float* x, int B, int S, int E, float drop_p,
+                   uint64_t drop_seed, void* stream);
+
+/* out = in * mask(p, seed) / (1-p), element index = row * cols + col; bf16 or f32, in place allowed.
+ * Backward of the dropout sites whose forward ran in a GEMM epilogue before a residual add
+ * (dropout1 / dropout2, torch transformer.py:977,982) and of pos_drop (train_vit.py:160). */
+int rvit_dropout_apply(const void* in, void* out, int dtype, int64_t rows, int cols, int64_t ld_in, int64_t ld_out,
+                       float p, uint64_t seed, void* stream);
+
+/* out[i] = 1 if element i of site (p, seed) is kept, else 0.  Test/debug aid: lets a host
+ * reference replay the masks the kernels used. */
+int rvit_dropout_mask(uint8_t* out, int64_t n, float p, uint64_t seed, void* stream);
 
 /* LayerNorm over the last axis, eps inside the sqrt, affine (torch transformer.py:774,947-950;
  * train_vit.py:119,166).  x: bf16/f32 [rows, ldx]; y: bf16/f32 [rows, ldy]; mean/rstd optional
@@ -135,13 +161,17 @@ int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx
 /* softmax(q k^T * scale) v per (batch, head), head_dim 64, S <= 256, no mask
  * (torch functional.py:6623-6631 -> scaled_dot_product_attention).
  *   qkv: bf16 [B*S, ldq] holding q | k | v column blocks of width H*64 (the in-proj output);
- *   out: bf16 [B*S, ldo], head h at columns h*64..; lse (optional) fp32 [B,H,S]. */
+ *   out: bf16 [B*S, ldo], head h at columns h*64..; lse (optional) fp32 [B,H,S].
+ *   drop_p > 0: dropout on the normalised probabilities (functional.py:6569-6570), element index =
+ *   ((b*H + h)*S + query)*S + key. */
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
-                  void* stream);
+                  float drop_p, uint64_t drop_seed, void* stream);
 
-/* Backward of rvit_attn_fwd: dqkv (same layout as qkv) from qkv, out, dout and the saved lse. */
+/* Backward of rvit_attn_fwd: dqkv (same layout as qkv) from qkv, out, dout and the saved lse;
+ * (drop_p, drop_seed) must be the forward's. */
 int rvit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
-                  int H, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, void* stream);
+                  int H, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, float drop_p,
+                  uint64_t drop_seed, void* stream);
 
 /* Cross-entropy with label smoothing, mean over the batch, value and gradient in one pass
  * (nn.CrossEntropyLoss(label_smoothing=...), train_vit.py:894,937).

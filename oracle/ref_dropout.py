@@ -1,0 +1,73 @@
+"""ORACLE — test infrastructure only.  Never imported by vit_amd/.
+
+Training-mode forward of the reference model with EXPLICIT dropout masks, so that a test can replay
+the masks the HIP kernels drew (vit_amd.ops.dropout_mask) and compare losses and gradients with
+autograd.  torch's own dropout cannot be steered from outside (Philox stream), so
+the six dropout sites are restated here on top of the oracle module's parameters:
+
+  pos_drop                         train_vit.py:100,160
+  attention-probability dropout    torch functional.py:6569-6570 (scaled_dot_product_attention dropout_p)
+  dropout1 (after out_proj)        torch transformer.py:977   (_sa_block)
+  dropout  (after GELU in the FFN) torch transformer.py:982   (_ff_block)
+  dropout2 (after linear2)         torch transformer.py:982
+  head dropout                     train_vit.py:125
+
+Everything else calls the same torch.nn modules / functionals as oracle/ref_model.py.  Pinned by
+tests/test_oracle.py: with all-ones masks (p = 0) it must reproduce CNNViTHybridRef.forward.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from .ref_model import CNNViTHybridRef
+
+
+def mask_shapes(ref: CNNViTHybridRef, B: int) -> Dict[object, tuple]:
+    """Site -> mask shape, in the element order the kernels index (row-major)."""
+    E = ref.pos_embed.shape[-1]
+    S = ref.num_patches + 1
+    H = ref.transformer.layers[0].self_attn.num_heads
+    shapes: Dict[object, tuple] = {"pos": (B, S, E), "head": (B, E // 2)}
+    for i in range(len(ref.transformer.layers)):
+        shapes[(i, "attn")] = (B, H, S, S)
+        shapes[(i, "proj")] = (B, S, E)
+        shapes[(i, "ffn")] = (B, S, 4 * E)
+        shapes[(i, "fc2")] = (B, S, E)
+    return shapes
+
+
+def forward_with_masks(ref: CNNViTHybridRef, x: torch.Tensor, masks: Dict[object, torch.Tensor], p: float,
+                       features_only: bool = False) -> torch.Tensor:
+    """Logits (or features) of `ref` with dropout sites multiplied by masks[site] / (1 - p)."""
+    k = 1.0 / (1.0 - p)
+    B = x.shape[0]
+    t = x
+    if ref.cnn_backbone is not None:
+        t = ref.cnn_backbone(t)[-1]
+    t = ref.patch_embed(t).flatten(2).transpose(1, 2)
+    t = torch.cat([ref.cls_token.expand(B, -1, -1), t], dim=1) + ref.pos_embed
+    t = t * masks["pos"] * k
+    for i, L in enumerate(ref.transformer.layers):
+        mha = L.self_attn
+        H = mha.num_heads
+        S, E = t.shape[1], t.shape[2]
+        Dh = E // H
+        h = L.norm1(t)
+        qkv = F.linear(h, mha.in_proj_weight, mha.in_proj_bias)
+        q, kk, v = (u.view(B, S, H, Dh).transpose(1, 2) for u in qkv.chunk(3, dim=-1))
+        a = torch.softmax(q @ kk.transpose(-1, -2) / math.sqrt(Dh), dim=-1)
+        a = a * masks[(i, "attn")] * k
+        o = (a @ v).transpose(1, 2).reshape(B, S, E)
+        t = t + mha.out_proj(o) * masks[(i, "proj")] * k
+        h = L.norm2(t)
+        f = F.gelu(L.linear1(h)) * masks[(i, "ffn")] * k
+        t = t + L.linear2(f) * masks[(i, "fc2")] * k
+    c = ref.norm(t[:, 0])
+    if features_only:
+        return c
+    hd = F.gelu(ref.head[0](c)) * masks["head"] * k
+    return ref.head[3](hd)

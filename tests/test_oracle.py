@@ -89,3 +89,22 @@ def test_bf16_emulation_distance_to_fp32_oracle():
     emu = forward_bf16_emulated(sd, x, R)
     assert (emu - want).abs().max() < 0.35
     assert (emu.argmax(1) == want.argmax(1)).all()
+
+
+def test_mask_replay_restatement_equals_module_forward():
+    """oracle/ref_dropout.py with all-ones masks must reproduce CNNViTHybridRef.forward (the torch modules
+    the reference instantiates), for the hybrid and the patch16 layouts, features and logits."""
+    from oracle.ref_dropout import forward_with_masks, mask_shapes
+    from oracle.ref_model import CNNViTHybridRef
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    for cfg in (dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=2, dropout=0.0, backbone="patch16"),
+                dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=2, dropout=0.0, backbone="resnet18")):
+        ref = CNNViTHybridRef(**cfg)
+        ref.load_state_dict(synth_state_dict({k: v.shape for k, v in ref.state_dict().items()}, 3))
+        ref.eval()
+        x = micro_doppler_batch(2, seed=8)
+        ones = {k: torch.ones(sh) for k, sh in mask_shapes(ref, 2).items()}
+        with torch.no_grad():
+            assert torch.allclose(forward_with_masks(ref, x, ones, 0.0), ref(x), rtol=1e-4, atol=1e-5)
+            assert torch.allclose(forward_with_masks(ref, x, ones, 0.0, features_only=True), ref.forward_features(x),
+                                  rtol=1e-4, atol=1e-5)

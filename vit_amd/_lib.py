@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  -- must be imported BEFORE librvit.so is loaded: torch ships its own
 #                              libamdhip64; loading ours first would bring up a second HIP runtime
 #                              that shares no device context or streams with torch's.
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librvit.so")
@@ -19,32 +19,36 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
+DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
 class RvitError(RuntimeError):
     """A librvit entry point returned a non-zero status."""
 
 
-P, I, L, F = c_void_p, c_int, c_int64, c_float
+P, I, L, F, U64 = c_void_p, c_int, c_int64, c_float, c_uint64
 
 # name -> (argtypes, restype), exactly mirroring include/rvit.h (tests/test_abi.py cross-checks it)
 SIGNATURES = {
     "rvit_version": ([], c_int),
     "rvit_last_error": ([], c_char_p),
-    "rvit_gemm_bf16": ([P, L, I, I, P, L, P, L, I, L, I, I, P, P, P, L, I, P, L, I, I, I, P, L, I, I, I, P], c_int),
+    "rvit_gemm_bf16": ([P, L, I, I, P, L, P, L, I, L, I, I, P, P, P, L, I, P, L, I, I, I, P, L, I, I, I, F, U64, I, P],
+                       c_int),
     "rvit_conv2d_fwd_bf16": ([P, P, P] + [I] * 12 + [P, P, P, I, I, P], c_int),
     "rvit_conv2d_dgrad_bf16": ([P, P, P] + [I] * 11 + [P, I, P], c_int),
-    "rvit_conv2d_tokens_fwd": ([P, P, P] + [I] * 12 + [P, P, I, P], c_int),
+    "rvit_conv2d_tokens_fwd": ([P, P, P] + [I] * 12 + [P, P, F, U64, I, P], c_int),
     "rvit_wgrad_bf16": ([P, L, I, I, P, L, I, I, P, L, L, I, I, I, I, P], c_int),
     "rvit_conv2d_wgrad_bf16": ([P, P, P] + [I] * 12 + [I, P], c_int),
     "rvit_input_pack_nhwc4": ([P, P] + [I] * 8 + [P], c_int),
     "rvit_maxpool3x3s2_nhwc": ([P, P, P] + [I] * 4 + [P], c_int),
-    "rvit_embed_cls": ([P, P, P, I, I, I, P], c_int),
+    "rvit_embed_cls": ([P, P, P, I, I, I, F, U64, P], c_int),
+    "rvit_dropout_apply": ([P, P, I, L, I, L, L, F, U64, P], c_int),
+    "rvit_dropout_mask": ([P, L, F, U64, P], c_int),
     "rvit_layernorm_fwd": ([P, I, L, P, P, P, I, L, P, P, L, I, F, P], c_int),
     "rvit_layernorm_bwd": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P], c_int),
-    "rvit_attn_fwd": ([P, P, P, I, I, I, L, L, F, P], c_int),
-    "rvit_attn_bwd": ([P, P, P, P, P, I, I, I, L, L, L, L, F, P], c_int),
+    "rvit_attn_fwd": ([P, P, P, I, I, I, L, L, F, F, U64, P], c_int),
+    "rvit_attn_bwd": ([P, P, P, P, P, I, I, I, L, L, L, L, F, F, U64, P], c_int),
     "rvit_ce_loss": ([P, L, P, P, P, L, P, L, I, I, I, F, F, P], c_int),
     "rvit_colsum_bf16": ([P, L, P, L, I, L, L, P], c_int),
     "rvit_batch_sum_f32": ([P, L, P, I, L, P], c_int),

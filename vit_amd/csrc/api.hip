@@ -36,8 +36,8 @@ const char* rvit_last_error(void) { return g_err; }
 int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int c_dtype, int64_t M, int N, int K, const float* scale, const float* bias,
                    const void* gate, int64_t ldg, int gate_mode, const void* R, int64_t ldr, int r_dtype,
-                   int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra, int tile,
-                   void* stream) {
+                   int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra, int drop_mode,
+                   float drop_p, uint64_t drop_seed, int tile, void* stream) {
   GemmArgs a{};
   a.A = (const bf16*)A; a.lda = lda; a.a_row_group = a_row_group; a.a_row_extra = a_row_extra;
   a.B = (const bf16*)B; a.ldb = ldb;
@@ -49,6 +49,9 @@ int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra,
   a.G = (const bf16*)gate; a.ldg = ldg; a.gate = gate ? gate_mode : 0;
   a.R = R; a.ldr = ldr; a.r_f32 = r_dtype == RVIT_F32; a.r_period = r_period;
   a.act = act; a.row_group = row_group; a.row_extra = row_extra; a.tile = tile;
+  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "gemm: drop_p=%f outside [0,1)", (double)drop_p);
+  a.drop_mode = drop_p > 0.f ? drop_mode : 0;
+  a.drop = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(c_dtype == RVIT_BF16 || c_dtype == RVIT_F32, "gemm: bad c_dtype %d", c_dtype);
   RVIT_CHECK_ARG(act >= 0 && act <= 2, "gemm: bad act %d", act);
   RVIT_CHECK_ARG(!gate || gate_mode == RVIT_GATE_GELU_GRAD || gate_mode == RVIT_GATE_RELU_MASK, "gemm: bad gate mode");
@@ -108,7 +111,7 @@ int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int
 
 int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* bias,
-                           const float* pos_embed, int tile, void* stream) {
+                           const float* pos_embed, float drop_p, uint64_t drop_seed, int tile, void* stream) {
   RVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
                  "conv_tokens: bad geometry");
   RVIT_CHECK_ARG((long)B * H * W < 0x7fffffffL, "conv_tokens: B*H*W exceeds 2^31 pixels");
@@ -120,6 +123,9 @@ int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, i
   a.R = pos_embed + Cout; a.ldr = Cout; a.r_f32 = 1; a.r_period = Ho * Wo;
   a.row_group = Ho * Wo; a.row_extra = 1;
   a.act = RVIT_ACT_NONE; a.tile = tile;
+  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "conv_tokens: drop_p=%f outside [0,1)", (double)drop_p);
+  a.drop_mode = drop_p > 0.f ? RVIT_DROP_POST_ACT : 0;  // pos_drop: after the position add
+  a.drop = make_drop_key(drop_p, drop_seed);
   bool vec = (Cout & 7) == 0 && aligned_to(tokens, 16) && aligned_to(pos_embed, 16);
   if (bias) vec = vec && aligned_to(bias, 16);
   a.vec = vec;
@@ -162,8 +168,19 @@ int rvit_maxpool3x3s2_nhwc(const void* x, void* y, void* argmax, int B, int H, i
   return rvit_maxpool_impl(x, y, argmax, B, H, W, C, (hipStream_t)stream);
 }
 
-int rvit_embed_cls(const float* cls_token, const float* pos_embed, float* x, int B, int S, int E, void* stream) {
-  return rvit_embed_cls_impl(cls_token, pos_embed, x, B, S, E, (hipStream_t)stream);
+int rvit_embed_cls(const float* cls_token, const float* pos_embed, float* x, int B, int S, int E, float drop_p,
+                   uint64_t drop_seed, void* stream) {
+  return rvit_embed_cls_impl(cls_token, pos_embed, x, B, S, E, drop_p, drop_seed, (hipStream_t)stream);
+}
+
+int rvit_dropout_apply(const void* in, void* out, int dtype, int64_t rows, int cols, int64_t ld_in, int64_t ld_out,
+                       float p, uint64_t seed, void* stream) {
+  RVIT_CHECK_ARG(dtype == RVIT_BF16 || dtype == RVIT_F32, "dropout_apply: bad dtype %d", dtype);
+  return rvit_dropout_apply_impl(in, out, dtype == RVIT_F32, rows, cols, ld_in, ld_out, p, seed, (hipStream_t)stream);
+}
+
+int rvit_dropout_mask(uint8_t* out, int64_t n, float p, uint64_t seed, void* stream) {
+  return rvit_dropout_mask_impl(out, n, p, seed, (hipStream_t)stream);
 }
 
 int rvit_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y,
@@ -181,13 +198,15 @@ int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx
 }
 
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
-                  void* stream) {
-  return rvit_attn_fwd_impl(qkv, out, lse, B, S, H, ldq, ldo, scale, (hipStream_t)stream);
+                  float drop_p, uint64_t drop_seed, void* stream) {
+  return rvit_attn_fwd_impl(qkv, out, lse, B, S, H, ldq, ldo, scale, drop_p, drop_seed, (hipStream_t)stream);
 }
 
 int rvit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
-                  int H, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, void* stream) {
-  return rvit_attn_bwd_impl(qkv, out, dout, lse, dqkv, B, S, H, ldq, ldo, lddo, lddq, scale, (hipStream_t)stream);
+                  int H, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, float drop_p,
+                  uint64_t drop_seed, void* stream) {
+  return rvit_attn_bwd_impl(qkv, out, dout, lse, dqkv, B, S, H, ldq, ldo, lddo, lddq, scale, drop_p, drop_seed,
+                            (hipStream_t)stream);
 }
 
 int rvit_ce_loss(const float* logits, int64_t ldl, const int64_t* labels, float* loss_sum, float* dlogits,

@@ -26,7 +26,8 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
 template <int NKB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int total_pairs, int S, int H,
-                                                       long ldq, long ldo, float scale_log2e, float scale) {
+                                                       long ldq, long ldo, float scale_log2e, float scale,
+                                                       DropKey dk) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int SP = 32 * NKB;
   constexpr int PAIR_BYTES = SP * (128 + V_PITCH);
@@ -110,6 +111,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         sum += pe;
       }
     sum += __shfl_xor(sum, 32, 64);
+    if (dk.thresh) {  // dropout on the (normalised) probabilities: element (pair, query, key)
+      const uint32_t base = (uint32_t)(((long)pair * S + query) * S);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sc[kb][r] *= drop_mult(dk, base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2);
+    }
 
     // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
     f32x16 o[2];
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 
 template <int NKB>
 int launch_attn_fwd(const bf16* qkv, bf16* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
-                    hipStream_t st) {
+                    DropKey dk, hipStream_t st) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int LDS = PAIRS * 32 * NKB * (128 + V_PITCH);
   static bool attr_set = false;
@@ -173,7 +182,7 @@ int launch_attn_fwd(const bf16* qkv, bf16* out, float* lse, int B, int S, int H,
   const int total = B * H;
   const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
   hipLaunchKernelGGL((attn_fwd_kernel<NKB>), dim3(grid), dim3(256), LDS, st, qkv, out, lse, total, S, H, ldq, ldo,
-                     scale * 1.44269504088896340736f, scale);
+                     scale * 1.44269504088896340736f, scale, dk);
   RVIT_CHECK_LAUNCH("attn_fwd");
   return RVIT_OK;
 }
@@ -199,7 +208,8 @@ template <int NKB>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
                                                        const bf16* __restrict__ dO, const float* __restrict__ lse,
                                                        bf16* __restrict__ dqkv, int total_pairs, int S, int H,
-                                                       long ldq, long ldo, long lddo, long lddq, float scale) {
+                                                       long ldq, long ldo, long lddo, long lddq, float scale,
+                                                       DropKey dk) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int SP = 32 * NKB;
   constexpr int TILE = SP * 128;
@@ -306,8 +316,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
           const float pe = exp2f(sa[r] * c_l2 - lv[e] * 1.44269504088896340736f);
-          sa[r] = pe;
-          dp[r] = pe * (dp[r] - dl[e]) * scale;
+          float mult = 1.f;
+          if (dk.thresh) {
+            const int query = qb * 32 + 8 * g + 4 * h2 + e;
+            mult = drop_mult(dk, (uint32_t)(((long)pair * S + query) * S + kb * 32 + r32));
+          }
+          sa[r] = pe * mult;                               // dropped probabilities feed dV
+          dp[r] = pe * (dp[r] * mult - dl[e]) * scale;     // dS = P * (dP_drop * mask/(1-p) - delta)
         }
       }
 #pragma unroll
@@ -390,7 +405,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
       for (int r = 0; r < 16; ++r) {
         const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
         const float pe = key < S ? exp2f(st[r] * c_l2 - lse_q) : 0.f;
-        dpt[r] = pe * (dpt[r] - del_q) * scale;
+        float mult = 1.f;
+        if (dk.thresh) mult = drop_mult(dk, (uint32_t)(((long)pair * S + qb * 32 + r32) * S + key));
+        dpt[r] = pe * (dpt[r] * mult - del_q) * scale;
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
 
 template <int NKB>
 int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, bf16* dqkv, int B, int S, int H,
-                    long ldq, long ldo, long lddo, long lddq, float scale, hipStream_t st) {
+                    long ldq, long ldo, long lddo, long lddq, float scale, DropKey dk, hipStream_t st) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int LDS = PAIRS * (4 * 32 * NKB * 128 + 32 * NKB * 8);
   static bool attr_set = false;
@@ -440,7 +457,7 @@ int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float*
   const int total = B * H;
   const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
   hipLaunchKernelGGL((attn_bwd_kernel<NKB>), dim3(grid), dim3(256), LDS, st, qkv, O, dO, lse, dqkv, total, S, H, ldq,
-                     ldo, lddo, lddq, scale);
+                     ldo, lddo, lddq, scale, dk);
   RVIT_CHECK_LAUNCH("attn_bwd");
   return RVIT_OK;
 }
@@ -448,8 +465,10 @@ int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float*
 }  // namespace
 
 int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
-                       hipStream_t st) {
+                       float drop_p, uint64_t drop_seed, hipStream_t st) {
   RVIT_CHECK_ARG(qkv && out, "attn_fwd: null pointer");
+  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (long)B * H * S * S < 0xffffffffL, "attn_fwd: bad dropout arguments");
+  const DropKey dk = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_fwd: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
   RVIT_CHECK_ARG(ldq >= 3L * H * 64 && (ldq & 7) == 0 && ldo >= (long)H * 64 && (ldo & 3) == 0,
                  "attn_fwd: bad pitches ldq=%ld ldo=%ld", ldq, ldo);
@@ -457,22 +476,25 @@ int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int
   const bf16* q = (const bf16*)qkv;
   bf16* o = (bf16*)out;
   switch ((S + 31) / 32) {
-    case 1: return launch_attn_fwd<1>(q, o, lse, B, S, H, ldq, ldo, scale, st);
-    case 2: return launch_attn_fwd<2>(q, o, lse, B, S, H, ldq, ldo, scale, st);
-    case 3: return launch_attn_fwd<3>(q, o, lse, B, S, H, ldq, ldo, scale, st);
-    case 4: return launch_attn_fwd<4>(q, o, lse, B, S, H, ldq, ldo, scale, st);
-    case 5: return launch_attn_fwd<5>(q, o, lse, B, S, H, ldq, ldo, scale, st);
-    case 6: return launch_attn_fwd<6>(q, o, lse, B, S, H, ldq, ldo, scale, st);
-    case 7: return launch_attn_fwd<7>(q, o, lse, B, S, H, ldq, ldo, scale, st);
-    case 8: return launch_attn_fwd<8>(q, o, lse, B, S, H, ldq, ldo, scale, st);
+    case 1: return launch_attn_fwd<1>(q, o, lse, B, S, H, ldq, ldo, scale, dk, st);
+    case 2: return launch_attn_fwd<2>(q, o, lse, B, S, H, ldq, ldo, scale, dk, st);
+    case 3: return launch_attn_fwd<3>(q, o, lse, B, S, H, ldq, ldo, scale, dk, st);
+    case 4: return launch_attn_fwd<4>(q, o, lse, B, S, H, ldq, ldo, scale, dk, st);
+    case 5: return launch_attn_fwd<5>(q, o, lse, B, S, H, ldq, ldo, scale, dk, st);
+    case 6: return launch_attn_fwd<6>(q, o, lse, B, S, H, ldq, ldo, scale, dk, st);
+    case 7: return launch_attn_fwd<7>(q, o, lse, B, S, H, ldq, ldo, scale, dk, st);
+    case 8: return launch_attn_fwd<8>(q, o, lse, B, S, H, ldq, ldo, scale, dk, st);
   }
   rvit_set_error("attn_fwd: S=%d unsupported", S);
   return RVIT_EUNSUPPORTED;
 }
 
 int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
-                       long ldq, long ldo, long lddo, long lddq, float scale, hipStream_t st) {
+                       long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,
+                       hipStream_t st) {
   RVIT_CHECK_ARG(qkv && O && dO && lse && dqkv, "attn_bwd: null pointer");
+  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (long)B * H * S * S < 0xffffffffL, "attn_bwd: bad dropout arguments");
+  const DropKey dk = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_bwd: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
   RVIT_CHECK_ARG(ldq >= 3L * H * 64 && lddq >= 3L * H * 64 && ldo >= (long)H * 64 && lddo >= (long)H * 64 &&
                      ((ldq | lddq | ldo | lddo) & 7) == 0,
@@ -482,14 +504,14 @@ int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const flo
   const bf16 *q = (const bf16*)qkv, *o = (const bf16*)O, *d = (const bf16*)dO;
   bf16* dq = (bf16*)dqkv;
   switch ((S + 31) / 32) {
-    case 1: return launch_attn_bwd<1>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
-    case 2: return launch_attn_bwd<2>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
-    case 3: return launch_attn_bwd<3>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
-    case 4: return launch_attn_bwd<4>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
-    case 5: return launch_attn_bwd<5>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
-    case 6: return launch_attn_bwd<6>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
-    case 7: return launch_attn_bwd<7>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
-    case 8: return launch_attn_bwd<8>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, st);
+    case 1: return launch_attn_bwd<1>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
+    case 2: return launch_attn_bwd<2>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
+    case 3: return launch_attn_bwd<3>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
+    case 4: return launch_attn_bwd<4>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
+    case 5: return launch_attn_bwd<5>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
+    case 6: return launch_attn_bwd<6>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
+    case 7: return launch_attn_bwd<7>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
+    case 8: return launch_attn_bwd<8>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
   }
   rvit_set_error("attn_bwd: S=%d unsupported", S);
   return RVIT_EUNSUPPORTED;

@@ -56,6 +56,31 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// Counter-based dropout (nn.Dropout of train_vit.py:100,107,125 and the attention-probability
+// dropout of torch functional.py:6569-6570).  Element `idx` of a dropout site keyed by (k0, k1) is
+// kept iff the top 24 bits of a two-round integer hash reach the threshold; forward and backward
+// regenerate the same decision from (key, idx), no mask is stored.
+__device__ __forceinline__ uint32_t rvit_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropKey {
+  uint32_t k0, k1, thresh;  // thresh = round(p * 2^24); 0 disables
+  float scale;              // 1 / (1 - p)
+};
+__host__ __device__ inline DropKey make_drop_key(float p, uint64_t seed) {
+  DropKey k;
+  k.k0 = (uint32_t)seed;
+  k.k1 = (uint32_t)(seed >> 32);
+  k.thresh = p > 0.f ? (uint32_t)(p * 16777216.0f + 0.5f) : 0u;
+  k.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  return k;
+}
+__device__ __forceinline__ float drop_mult(const DropKey& k, uint32_t idx) {
+  const uint32_t h = rvit_mix32(rvit_mix32(idx + k.k0) ^ k.k1);
+  return (h >> 8) >= k.thresh ? k.scale : 0.f;
+}
+
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   union { bf16 h[2]; uint32_t u; } r;
   r.h[0] = (bf16)lo;

@@ -91,12 +91,50 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const bf16* __restrict__ x
 
 // x[b, 0, :] = cls_token + pos_embed[0]   (train_vit.py:155-159), fp32 residual stream.
 __global__ __launch_bounds__(256) void embed_cls_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
-                                                        float* __restrict__ x, int B, int S, int E) {
+                                                        float* __restrict__ x, int B, int S, int E, DropKey dk) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * E) return;
   const int e = (int)(idx % E);
   const long b = idx / E;
-  x[b * S * E + e] = cls[e] + pos[e];
+  float v = cls[e] + pos[e];
+  if (dk.thresh) v *= drop_mult(dk, (uint32_t)(b * S * E + e));  // pos_drop, element index of the token matrix
+  x[b * S * E + e] = v;
+}
+
+// out = in * mask / (1-p) with the mask of site (p, seed), element index = row * cols + col.
+// Backward of the dropout sites whose forward ran inside a GEMM epilogue; in-place allowed.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const T* __restrict__ in, T* __restrict__ out, long rows,
+                                                            int cols, long ld_in, long ld_out, DropKey dk) {
+  const int c4 = cols >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * c4) return;
+  const long r = idx / c4;
+  const int c = (int)(idx - r * c4) * 4;
+  const uint32_t di = (uint32_t)(r * cols + c);
+  float v[4];
+  if constexpr (sizeof(T) == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(in + r * ld_in + c);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  } else {
+    const uint2 q = *reinterpret_cast<const uint2*>(in + r * ld_in + c);
+    v[0] = bf16_lo(q.x); v[1] = bf16_hi(q.x); v[2] = bf16_lo(q.y); v[3] = bf16_hi(q.y);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] *= drop_mult(dk, di + e);
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<float4*>(out + r * ld_out + c) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint2 w;
+    w.x = pack_bf16x2(v[0], v[1]);
+    w.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(out + r * ld_out + c) = w;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, long n, DropKey dk) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = drop_mult(dk, (uint32_t)i) != 0.f ? 1 : 0;
 }
 
 }  // namespace
@@ -126,10 +164,43 @@ int rvit_maxpool_impl(const void* x, void* y, void* argmax, int B, int H, int W,
   return RVIT_OK;
 }
 
-int rvit_embed_cls_impl(const float* cls, const float* pos, float* x, int B, int S, int E, hipStream_t st) {
+int rvit_embed_cls_impl(const float* cls, const float* pos, float* x, int B, int S, int E, float drop_p,
+                        uint64_t drop_seed, hipStream_t st) {
   RVIT_CHECK_ARG(cls && pos && x && B > 0 && S > 0 && E > 0, "embed_cls: bad arguments");
+  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (long)B * S * E < 0xffffffffL, "embed_cls: bad dropout arguments");
   const long total = (long)B * E;
-  hipLaunchKernelGGL(embed_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cls, pos, x, B, S, E);
+  hipLaunchKernelGGL(embed_cls_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cls, pos, x, B, S, E,
+                     make_drop_key(drop_p, drop_seed));
   RVIT_CHECK_LAUNCH("embed_cls");
+  return RVIT_OK;
+}
+
+int rvit_dropout_apply_impl(const void* in, void* out, int f32, long rows, int cols, long ld_in, long ld_out,
+                            float p, uint64_t seed, hipStream_t st) {
+  RVIT_CHECK_ARG(in && out && rows >= 0 && cols > 0 && (cols & 3) == 0 && ld_in >= cols && ld_out >= cols,
+                 "dropout_apply: bad shape");
+  RVIT_CHECK_ARG((ld_in & 3) == 0 && (ld_out & 3) == 0 && ((uintptr_t)in & (f32 ? 15 : 7)) == 0 &&
+                     ((uintptr_t)out & (f32 ? 15 : 7)) == 0,
+                 "dropout_apply: alignment");
+  RVIT_CHECK_ARG(p >= 0.f && p < 1.f && rows * cols < 0xffffffffL, "dropout_apply: bad p or too many elements");
+  if (rows == 0) return RVIT_OK;
+  const long total = rows * (cols >> 2);
+  const DropKey dk = make_drop_key(p, seed);
+  if (f32)
+    hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)in, (float*)out, rows, cols, ld_in, ld_out, dk);
+  else
+    hipLaunchKernelGGL(dropout_apply_kernel<bf16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const bf16*)in, (bf16*)out, rows, cols, ld_in, ld_out, dk);
+  RVIT_CHECK_LAUNCH("dropout_apply");
+  return RVIT_OK;
+}
+
+int rvit_dropout_mask_impl(uint8_t* out, long n, float p, uint64_t seed, hipStream_t st) {
+  RVIT_CHECK_ARG(out && n >= 0 && n < 0xffffffffL && p >= 0.f && p < 1.f, "dropout_mask: bad arguments");
+  if (n == 0) return RVIT_OK;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n,
+                     make_drop_key(p, seed));
+  RVIT_CHECK_LAUNCH("dropout_mask");
   return RVIT_OK;
 }

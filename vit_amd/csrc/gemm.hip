@@ -283,6 +283,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>(p.C2 + orow * p.ldc2 + n) = o;
       }
+      if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) {
+        const uint32_t di = (uint32_t)(orow * p.N + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
+      }
       if (p.R) {
         if (p.r_f32) {
           const float* rp = (const float*)p.R + rrow * p.ldr + n;
@@ -301,6 +306,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
       } else if (p.act == RVIT_ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if (p.drop_mode == RVIT_DROP_POST_ACT) {
+        const uint32_t di = (uint32_t)(orow * p.N + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
       }
       if (p.c_f32) {
         float* cp = (float*)p.C + orow * p.ldc + n;
@@ -324,10 +334,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
           x *= p.gate == RVIT_GATE_GELU_GRAD ? gelu_erf_grad(gv) : (gv > 0.f ? 1.f : 0.f);
         }
         if (p.C2) p.C2[orow * p.ldc2 + n + e] = (bf16)x;
+        if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) x *= drop_mult(p.drop, (uint32_t)(orow * p.N + n + e));
         if (p.R) x += p.r_f32 ? ((const float*)p.R)[rrow * p.ldr + n + e]
                               : (float)((const bf16*)p.R)[rrow * p.ldr + n + e];
         if (p.act == RVIT_ACT_RELU) x = fmaxf(x, 0.f);
         else if (p.act == RVIT_ACT_GELU) x = gelu_erf(x);
+        if (p.drop_mode == RVIT_DROP_POST_ACT) x *= drop_mult(p.drop, (uint32_t)(orow * p.N + n + e));
         if (p.c_f32) ((float*)p.C)[orow * p.ldc + n + e] = x;
         else ((bf16*)p.C)[orow * p.ldc + n + e] = (bf16)x;
       }
@@ -379,6 +391,11 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
                    "conv: bad gather geometry Cpix=%d seg_len=%d KW=%d", a.Cpix, a.seg_len, a.KW);
     RVIT_CHECK_ARG(a.H < 20000 && a.W < 20000, "conv: image too large for packed coordinates");
     RVIT_CHECK_ARG(!a.transposed || a.stride == 1 || a.stride == 2, "conv dgrad: stride must be 1 or 2");
+  }
+  if (a.drop_mode) {
+    RVIT_CHECK_ARG(a.drop_mode == RVIT_DROP_PRE_RESIDUAL || a.drop_mode == RVIT_DROP_POST_ACT, "gemm: bad drop_mode");
+    const long out_rows = a.row_group > 0 ? (a.M / a.row_group + 1) * (long)(a.row_group + a.row_extra) : a.M;
+    RVIT_CHECK_ARG(out_rows * a.N < 0xffffffffL, "gemm: dropout element index exceeds 32 bits");
   }
   if (a.gate) {
     RVIT_CHECK_ARG(a.G && a.ldg >= a.N, "gemm: gate operand missing");

@@ -37,6 +37,8 @@ struct GemmArgs {
   int row_extra;
   int vec;           // 1: N, ld* and pointers allow 8-wide (16-byte) vector epilogue accesses
   int tile;          // 0 = auto, else forced tile config (tests)
+  int drop_mode;     // 0 none, RVIT_DROP_PRE_RESIDUAL, RVIT_DROP_POST_ACT; element index = out_row * N + col
+  DropKey drop;
 };
 
 int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream);
@@ -67,13 +69,18 @@ int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx,
                             const float* gamma, float* dxs, long lddx, int accumulate, void* dx_bf16, long lddb,
                             float* dgamma, float* dbeta, long rows, int E, hipStream_t st);
 int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
-                       hipStream_t st);
+                       float drop_p, uint64_t drop_seed, hipStream_t st);
 int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
-                       long ldq, long ldo, long lddo, long lddq, float scale, hipStream_t st);
+                       long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,
+                       hipStream_t st);
+int rvit_dropout_apply_impl(const void* in, void* out, int f32, long rows, int cols, long ld_in, long ld_out,
+                            float p, uint64_t seed, hipStream_t st);
+int rvit_dropout_mask_impl(uint8_t* out, long n, float p, uint64_t seed, hipStream_t st);
 int rvit_input_pack_impl(const float* x, void* out, int B, int C, int H, int W, int Hp, int Wp, int pt, int pl,
                          hipStream_t st);
 int rvit_maxpool_impl(const void* x, void* y, void* argmax, int B, int H, int W, int C, hipStream_t st);
-int rvit_embed_cls_impl(const float* cls, const float* pos, float* x, int B, int S, int E, hipStream_t st);
+int rvit_embed_cls_impl(const float* cls, const float* pos, float* x, int B, int S, int E, float drop_p,
+                        uint64_t drop_seed, hipStream_t st);
 int rvit_ce_loss_impl(const float* logits, long ldl, const long* labels, float* loss_sum, float* dlogits, long lddl,
                       void* dlogits_bf16, long lddb, int B, int C, int C_pad, float eps, float gscale, hipStream_t st);
 int rvit_colsum_impl(const void* a, long lda, float* out, long M, int N, long row_group, long row_extra,

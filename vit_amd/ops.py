@@ -6,7 +6,7 @@ module has a non-HIP implementation.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
@@ -83,6 +83,19 @@ def _rows2d(t: torch.Tensor, what: str):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
+_DROP_POS = {"pre_residual": _lib.DROP_PRE_RESIDUAL, "post_act": _lib.DROP_POST_ACT}
+
+
+def _drop(drop):
+    """(position, p, seed) -> (mode, p, seed) for the C ABI; None or p == 0 disables."""
+    if drop is None or drop[1] == 0.0:
+        return 0, 0.0, 0
+    pos, p, seed = drop
+    if pos not in _DROP_POS or not (0.0 <= p < 1.0):
+        raise ValueError(f"dropout: bad spec {drop!r}")
+    return _DROP_POS[pos], float(p), int(seed) & 0xFFFFFFFFFFFFFFFF
+
+
 def _vec_f32(v, n, what):
     if v is not None and (v.dtype != torch.float32 or v.numel() != n or not v.is_contiguous()):
         raise ValueError(f"{what} must be contiguous float32 [{n}]")
@@ -95,10 +108,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
          scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, residual_period: int = 0,
          act: Optional[str] = None, preact: Optional[torch.Tensor] = None, row_group: int = 0, row_extra: int = 0,
          gate: Optional[torch.Tensor] = None, gate_mode: Optional[str] = None, a_rows: Optional[int] = None,
-         a_row_group: int = 0, a_row_extra: int = 0, tile: int = 0) -> torch.Tensor:
+         a_row_group: int = 0, a_row_extra: int = 0, drop: Optional[Tuple[str, float, int]] = None,
+         tile: int = 0) -> torch.Tensor:
     """out = act(gate(scale * (a @ w.T) + bias) + residual); a [M,K] bf16, w [N,K] bf16.
 
-    a_rows/a_row_group/a_row_extra: use `a_rows` logical rows of `a` through the row remap."""
+    a_rows/a_row_group/a_row_extra: use `a_rows` logical rows of `a` through the row remap.
+    drop = (position, p, seed): dropout in the epilogue, position "pre_residual" | "post_act"."""
     _need_cuda(a, w, out, bias, scale, residual, preact, gate)
     Ma, K, lda = _rows2d(a, "gemm a")
     M = Ma if a_rows is None else a_rows
@@ -131,6 +146,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
             raise ValueError("gemm: gate must be bf16 [rows, N] with gate_mode gelu_grad|relu_mask")
     _vec_f32(bias, N, "gemm: bias")
     _vec_f32(scale, N, "gemm: scale")
+    d_mode, d_p, d_seed = _drop(drop)
     lib = _lib.load()
     nb = (M * K + N * K) * 2 + M * N * out.element_size() + (M * N * residual.element_size() if residual is not None
                                                              and not residual_period else 0)
@@ -138,7 +154,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
         check(lib.rvit_gemm_bf16(a.data_ptr(), lda, a_row_group, a_row_extra, w.data_ptr(), ldb, out.data_ptr(), ldc,
                                  _dt(out), M, N, K, _ptr(scale), _ptr(bias), _ptr(gate), ldg, _GATE[gate_mode],
                                  _ptr(residual), ldr, r_dt, residual_period, _ACT[act], _ptr(preact), ldp, row_group,
-                                 row_extra, tile, _stream()), "rvit_gemm_bf16")
+                                 row_extra, d_mode, d_p, d_seed, tile, _stream()), "rvit_gemm_bf16")
     return out
 
 
@@ -173,8 +189,9 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
 
 def conv2d_tokens(x: torch.Tensor, w: torch.Tensor, tokens: torch.Tensor, pos_embed: torch.Tensor, *, kh: int,
                   kw: int, stride: int, pad: int, seg_len: int, ho: int, wo: int,
-                  bias: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
-    """Patch conv into the fp32 token stream: tokens[b,1+p] = conv(x,w)[b,p] + bias + pos_embed[1+p]."""
+                  bias: Optional[torch.Tensor] = None, drop_p: float = 0.0, drop_seed: int = 0,
+                  tile: int = 0) -> torch.Tensor:
+    """Patch conv into the fp32 token stream: tokens[b,1+p] = drop(conv(x,w)[b,p] + bias + pos_embed[1+p])."""
     _need_cuda(x, w, tokens, pos_embed, bias)
     B, H, W, Cpix = x.shape
     Bt, S, E = tokens.shape
@@ -190,7 +207,8 @@ def conv2d_tokens(x: torch.Tensor, w: torch.Tensor, tokens: torch.Tensor, pos_em
     with _Span("conv2d_tokens", 2 * B * ho * wo * E * true_k, _nbytes(x, w, tokens)):
         check(_lib.load().rvit_conv2d_tokens_fwd(x.data_ptr(), w.data_ptr(), tokens.data_ptr(), B, H, W, Cpix,
                                                  seg_len, kh, kw, stride, pad, ho, wo, E, _ptr(bias),
-                                                 pos_embed.data_ptr(), tile, _stream()), "rvit_conv2d_tokens_fwd")
+                                                 pos_embed.data_ptr(), float(drop_p), int(drop_seed), tile, _stream()),
+              "rvit_conv2d_tokens_fwd")
     return tokens
 
 
@@ -226,8 +244,9 @@ def maxpool3x3s2(x: torch.Tensor, out: torch.Tensor, argmax: Optional[torch.Tens
     return out
 
 
-def embed_cls(cls_token: torch.Tensor, pos_embed: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """x[b,0,:] = cls_token + pos_embed[0]; x fp32 [B,S,E] contiguous."""
+def embed_cls(cls_token: torch.Tensor, pos_embed: torch.Tensor, x: torch.Tensor, drop_p: float = 0.0,
+              drop_seed: int = 0) -> torch.Tensor:
+    """x[b,0,:] = drop(cls_token + pos_embed[0]); x fp32 [B,S,E] contiguous."""
     _need_cuda(cls_token, pos_embed, x)
     B, S, E = x.shape
     if x.dtype != torch.float32 or not x.is_contiguous():
@@ -237,8 +256,29 @@ def embed_cls(cls_token: torch.Tensor, pos_embed: torch.Tensor, x: torch.Tensor)
         raise ValueError("embed_cls: cls/pos must be contiguous float32")
     with _Span("embed_cls", 0, B * E * 4):
         check(_lib.load().rvit_embed_cls(cls_token.data_ptr(), pos_embed.data_ptr(), x.data_ptr(), B, S, E,
-                                         _stream()), "rvit_embed_cls")
+                                         float(drop_p), int(drop_seed), _stream()), "rvit_embed_cls")
     return x
+
+
+def dropout_apply(x: torch.Tensor, out: torch.Tensor, p: float, seed: int) -> torch.Tensor:
+    """out = x * mask(p, seed) / (1-p), element index = row * cols + col; bf16 or f32 [rows, cols]."""
+    _need_cuda(x, out)
+    rows, cols, ld_in = _rows2d(x, "dropout_apply x")
+    ro, co, ld_out = _rows2d(out, "dropout_apply out")
+    if (ro, co) != (rows, cols) or x.dtype != out.dtype or x.dtype not in (BF16, torch.float32):
+        raise ValueError("dropout_apply: shape/dtype mismatch")
+    with _Span("dropout_apply", 0, 2 * rows * cols * x.element_size()):
+        check(_lib.load().rvit_dropout_apply(x.data_ptr(), out.data_ptr(), _dt(x), rows, cols, ld_in, ld_out, float(p),
+                                             int(seed), _stream()), "rvit_dropout_apply")
+    return out
+
+
+def dropout_mask(n: int, p: float, seed: int, device) -> torch.Tensor:
+    """uint8 [n]: 1 where element i of the dropout site (p, seed) is kept (test/debug aid)."""
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    _need_cuda(out)
+    check(_lib.load().rvit_dropout_mask(out.data_ptr(), n, float(p), int(seed), _stream()), "rvit_dropout_mask")
+    return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float = 1e-5,
@@ -261,7 +301,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, lse: Optional[torch.Tensor] = None,
-              scale: Optional[float] = None) -> torch.Tensor:
+              scale: Optional[float] = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
     """qkv bf16 [B*S, 3*H*64] (q|k|v), out bf16 [B*S, H*64]; softmax(q k^T scale) v per head."""
     _need_cuda(qkv, out, lse)
     T, W3, ldq = _rows2d(qkv, "attention qkv")
@@ -273,8 +313,8 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, lse:
     _vec_f32(lse, B * H * S, "attention: lse")
     sc = (1.0 / 8.0) if scale is None else float(scale)
     with _Span("attn_fwd", 4 * B * H * S * S * 64, _nbytes(qkv, out, lse)):
-        check(_lib.load().rvit_attn_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, S, H, ldq, ldo, sc, _stream()),
-              "rvit_attn_fwd")
+        check(_lib.load().rvit_attn_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, S, H, ldq, ldo, sc,
+                                        float(drop_p), int(drop_seed), _stream()), "rvit_attn_fwd")
     return out
 
 
@@ -362,7 +402,8 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: t
 
 
 def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, dqkv: torch.Tensor,
-                  B: int, S: int, H: int, scale: Optional[float] = None) -> torch.Tensor:
+                  B: int, S: int, H: int, scale: Optional[float] = None, drop_p: float = 0.0,
+                  drop_seed: int = 0) -> torch.Tensor:
     _need_cuda(qkv, out, dout, lse, dqkv)
     T, W3, ldq = _rows2d(qkv, "attention_bwd qkv")
     _, Wo, ldo = _rows2d(out, "attention_bwd out")
@@ -375,7 +416,8 @@ def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse:
     sc = (1.0 / 8.0) if scale is None else float(scale)
     with _Span("attn_bwd", 10 * B * H * S * S * 64, _nbytes(qkv, out, dout, dqkv)):
         check(_lib.load().rvit_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                        dqkv.data_ptr(), B, S, H, ldq, ldo, lddo, lddq, sc, _stream()), "rvit_attn_bwd")
+                                        dqkv.data_ptr(), B, S, H, ldq, ldo, lddo, lddq, sc, float(drop_p),
+                                        int(drop_seed), _stream()), "rvit_attn_bwd")
     return dqkv
 
 

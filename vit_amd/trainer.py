@@ -77,6 +77,24 @@ class _GradLayout:
         self.param_order = [n for n, _ in model.named_parameters()]
 
 
+# dropout sites of the reference model (train_vit.py:100,107,125; torch transformer.py:977-982)
+SITE_POS, SITE_HEAD = 0, 1
+SITE_ATTN, SITE_PROJ, SITE_FFN, SITE_FC2 = 0, 1, 2, 3
+_M64 = (1 << 64) - 1
+
+
+def _layer_site(layer: int, which: int) -> int:
+    return 4 + 4 * layer + which
+
+
+def _site_seed(base: int, site: int) -> int:
+    """splitmix64 of (step seed, site id) -> the 64-bit key of one dropout site."""
+    z = (base + 0x9E3779B97F4A7C15 * (site + 1)) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
 class TrainEngine:
     def __init__(self, model):
         self.m = model
@@ -189,6 +207,7 @@ class TrainEngine:
         b["dxs"] = torch.empty(B, S, E, **f)
         b["dxs_bf"] = torch.empty(T, E, **z)
         b["d_e"] = torch.empty(T, E, **z)
+        b["d_e2"] = torch.empty(T, E, **z)
         b["d_3e"] = torch.empty(T, 3 * E, **z)
         b["d_4e"] = torch.empty(T, 4 * E, **z)
         b["d_h0"] = torch.empty(B, E // 2, **z)
@@ -246,16 +265,18 @@ class TrainEngine:
 
     def forward(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
         m = self.m
-        if m.dropout != 0.0:
-            raise NotImplementedError(
-                "training through librvit currently requires dropout=0.0 (the six dropout sites of the reference, "
-                "train_vit.py:100,107,125, are not implemented on the HIP path yet); construct the model with "
-                "dropout=0.0")
         P = self.pack()
         B = x.shape[0]
         E, S, H, NP = m.embed_dim, m.num_patches + 1, m.num_heads, m.num_patches
         T = B * S
         b = self.buffers(B, x.device)
+        # dropout (train_vit.py:100,107,125): one 62-bit draw per step from torch's CPU generator (so
+        # torch.manual_seed reproduces a run and ranks seeded differently drop differently), expanded
+        # into one key per site; the backward pass regenerates the masks from the same keys
+        dp = float(m.dropout)
+        base = int(torch.randint(0, 1 << 62, (1,)).item()) if dp > 0.0 else 0
+        b["drop"] = (dp, base)
+        sd = lambda site: _site_seed(base, site)  # noqa: E731
         xin = x.detach().float().contiguous()
         xs = b["xs"]
         x0 = xs[0]
@@ -264,22 +285,28 @@ class TrainEngine:
             feat = self._stem_forward(P, b, B)
             b["feat"] = feat
             ops.gemm(feat.view(B * NP, -1), P["pe_w"], x0.view(T, E), bias=m.patch_embed.bias.detach(),
-                     residual=m.pos_embed.detach().view(S, E)[1:], residual_period=NP, row_group=NP, row_extra=1)
+                     residual=m.pos_embed.detach().view(S, E)[1:], residual_period=NP, row_group=NP, row_extra=1,
+                     drop=("post_act", dp, sd(SITE_POS)))
         else:
             ops.input_pack(xin, b["img"], 0, 0)
             ops.conv2d_tokens(b["img"], P["pe_w"], x0, m.pos_embed.detach().view(S, E), kh=16, kw=1, stride=16, pad=0,
-                              seg_len=64, ho=14, wo=14, bias=m.patch_embed.bias.detach())
-        ops.embed_cls(m.cls_token.detach().view(-1), m.pos_embed.detach().view(S, E), x0)
+                              seg_len=64, ho=14, wo=14, bias=m.patch_embed.bias.detach(), drop_p=dp,
+                              drop_seed=sd(SITE_POS))
+        ops.embed_cls(m.cls_token.detach().view(-1), m.pos_embed.detach().view(S, E), x0, dp, sd(SITE_POS))
         for i, (L, W) in enumerate(zip(m.transformer.layers, P["layers"])):
             xi, xm, xo = xs[2 * i].view(T, E), xs[2 * i + 1].view(T, E), xs[2 * i + 2].view(T, E)
             st = b["stat"][i]
             ops.layernorm(xi, L.norm1.weight.detach(), L.norm1.bias.detach(), b["ln1"][i], L.norm1.eps, st[0], st[1])
             ops.gemm(b["ln1"][i], W["qkv_w"], b["qkv"][i], bias=L.self_attn.in_proj_bias.detach())
-            ops.attention(b["qkv"][i], b["att"][i], B, S, H, lse=b["lse"][i])
-            ops.gemm(b["att"][i], W["out_w"], xm, bias=L.self_attn.out_proj.bias.detach(), residual=xi)
+            ops.attention(b["qkv"][i], b["att"][i], B, S, H, lse=b["lse"][i], drop_p=dp,
+                          drop_seed=sd(_layer_site(i, SITE_ATTN)))
+            ops.gemm(b["att"][i], W["out_w"], xm, bias=L.self_attn.out_proj.bias.detach(), residual=xi,
+                     drop=("pre_residual", dp, sd(_layer_site(i, SITE_PROJ))))
             ops.layernorm(xm, L.norm2.weight.detach(), L.norm2.bias.detach(), b["ln2"][i], L.norm2.eps, st[2], st[3])
-            ops.gemm(b["ln2"][i], W["fc1_w"], b["h"][i], bias=L.linear1.bias.detach(), act="gelu", preact=b["u"][i])
-            ops.gemm(b["h"][i], W["fc2_w"], xo, bias=L.linear2.bias.detach(), residual=xm)
+            ops.gemm(b["ln2"][i], W["fc1_w"], b["h"][i], bias=L.linear1.bias.detach(), act="gelu", preact=b["u"][i],
+                     drop=("post_act", dp, sd(_layer_site(i, SITE_FFN))))
+            ops.gemm(b["h"][i], W["fc2_w"], xo, bias=L.linear2.bias.detach(), residual=xm,
+                     drop=("pre_residual", dp, sd(_layer_site(i, SITE_FC2))))
         xf = xs[-1]
         cls_rows = xf.view(B, S * E)[:, :E]
         cs = b["cls_stat"]
@@ -288,7 +315,8 @@ class TrainEngine:
             ops.layernorm(cls_rows, m.norm.weight.detach(), m.norm.bias.detach(), out, m.norm.eps, cs[0], cs[1])
             return out
         ops.layernorm(cls_rows, m.norm.weight.detach(), m.norm.bias.detach(), b["cls_ln"], m.norm.eps, cs[0], cs[1])
-        ops.gemm(b["cls_ln"], P["h0_w"], b["h0"], bias=m.head["0"].bias.detach(), act="gelu", preact=b["u0"])
+        ops.gemm(b["cls_ln"], P["h0_w"], b["h0"], bias=m.head["0"].bias.detach(), act="gelu", preact=b["u0"],
+                 drop=("post_act", dp, sd(SITE_HEAD)))
         logits = torch.empty(B, m.num_classes, dtype=F32, device=x.device)
         ops.gemm(b["h0"], P["h3_w"], logits, bias=m.head["3"].bias.detach())
         return logits
@@ -372,6 +400,8 @@ class TrainEngine:
         E, S, H, NP, C = m.embed_dim, m.num_patches + 1, m.num_heads, m.num_patches, m.num_classes
         T = B * S
         L = self.layout
+        dp, base = b["drop"]
+        sd = lambda site: _site_seed(base, site)  # noqa: E731
         flat = torch.zeros(L.total, dtype=F32, device=dev)
         if self.reducer is not None:
             self.reducer.begin_step()
@@ -393,7 +423,8 @@ class TrainEngine:
             b["tmp16"].zero_()
             ops.colsum(dl16, b["tmp16"])
             g("head.3.bias").copy_(b["tmp16"][:C])
-            ops.gemm(dl16, P["h3_wt"], b["d_h0"], gate=b["u0"], gate_mode="gelu_grad")
+            ops.gemm(dl16, P["h3_wt"], b["d_h0"], gate=b["u0"], gate_mode="gelu_grad",
+                     drop=("post_act", dp, sd(SITE_HEAD)))
             ops.wgrad(b["d_h0"], b["cls_ln"], g2("head.0.weight", E // 2))
             ops.colsum(b["d_h0"], g("head.0.bias"))
             dcls = ops.gemm(b["d_h0"], P["h0_wt"], b["d_cls"])
@@ -407,26 +438,37 @@ class TrainEngine:
             xi, xm = xs[2 * i].view(T, E), xs[2 * i + 1].view(T, E)
             st = b["stat"][i]
             # ---- MLP block:  xo = xm + fc2(gelu(fc1(LN2(xm))))
-            ops.wgrad(dxs_bf, b["h"][i], g2(p + "linear2.weight", E))
-            ops.colsum(dxs_bf, g(p + "linear2.bias"))
-            ops.gemm(dxs_bf, W["fc2_wt"], b["d_4e"], gate=b["u"][i], gate_mode="gelu_grad")
+            dy = dxs_bf  # gradient of the block output; dropout2 masks what reaches linear2
+            if dp > 0.0:
+                dy = ops.dropout_apply(dxs_bf, b["d_e"], dp, sd(_layer_site(i, SITE_FC2)))
+            ops.wgrad(dy, b["h"][i], g2(p + "linear2.weight", E))
+            ops.colsum(dy, g(p + "linear2.bias"))
+            ops.gemm(dy, W["fc2_wt"], b["d_4e"], gate=b["u"][i], gate_mode="gelu_grad",
+                     drop=("post_act", dp, sd(_layer_site(i, SITE_FFN))))
             ops.wgrad(b["d_4e"], b["ln2"][i], g2(p + "linear1.weight", 4 * E))
             ops.colsum(b["d_4e"], g(p + "linear1.bias"))
             ops.gemm(b["d_4e"], W["fc1_wt"], b["d_e"])
             ops.layernorm_bwd(b["d_e"], xm, st[2], st[3], Lm.norm2.weight.detach(), dx2, g(p + "norm2.weight"),
                               g(p + "norm2.bias"), accumulate=True, dx_bf16=dxs_bf)
             # ---- attention block:  xm = xi + out_proj(attn(qkv(LN1(xi))))
-            ops.wgrad(dxs_bf, b["att"][i], g2(p + "self_attn.out_proj.weight", E))
-            ops.colsum(dxs_bf, g(p + "self_attn.out_proj.bias"))
-            ops.gemm(dxs_bf, W["out_wt"], b["d_e"])
-            ops.attention_bwd(b["qkv"][i], b["att"][i], b["d_e"], b["lse"][i], b["d_3e"], B, S, H)
+            dy = dxs_bf
+            if dp > 0.0:
+                dy = ops.dropout_apply(dxs_bf, b["d_e2"], dp, sd(_layer_site(i, SITE_PROJ)))
+            ops.wgrad(dy, b["att"][i], g2(p + "self_attn.out_proj.weight", E))
+            ops.colsum(dy, g(p + "self_attn.out_proj.bias"))
+            ops.gemm(dy, W["out_wt"], b["d_e"])
+            ops.attention_bwd(b["qkv"][i], b["att"][i], b["d_e"], b["lse"][i], b["d_3e"], B, S, H, drop_p=dp,
+                              drop_seed=sd(_layer_site(i, SITE_ATTN)))
             ops.wgrad(b["d_3e"], b["ln1"][i], g2(p + "self_attn.in_proj_weight", 3 * E))
             ops.colsum(b["d_3e"], g(p + "self_attn.in_proj_bias"))
             ops.gemm(b["d_3e"], W["qkv_wt"], b["d_e"])
             ops.layernorm_bwd(b["d_e"], xi, st[0], st[1], Lm.norm1.weight.detach(), dx2, g(p + "norm1.weight"),
                               g(p + "norm1.bias"), accumulate=True, dx_bf16=dxs_bf)
             self._maybe_reduce(flat, p + "norm1.bias")
-        # ---- token assembly: x0[b,0] = cls + pos[0]; x0[b,1+p] = patch[b,p] + pos[1+p]
+        # ---- token assembly: x0 = pos_drop([cls + pos[0]; patch[b,p] + pos[1+p]])
+        if dp > 0.0:
+            ops.dropout_apply(dx2, dx2, dp, sd(SITE_POS))
+            ops.dropout_apply(dxs_bf, dxs_bf, dp, sd(SITE_POS))
         ops.batch_sum(dxs.view(B, S * E), g("pos_embed"))
         g("cls_token").copy_(g("pos_embed")[:E])
         if m.cnn_backbone is not None:
