@@ -1,0 +1,86 @@
+"""Generates tests/golden/: run in the build container (reads /root/reference for the images only).
+
+  images/<Class>.png     one real spectrogram per class: the first file (sorted) of
+                         /root/reference/splits/test/<Class>/, converted to 8-bit luma and resized
+                         to 224x224 bilinear (the reference's own preprocessing up to ToTensor,
+                         infer.py:346-353) -- data, ~30 KB each
+  manifest.json          source file name of every image, torch version, thread count
+  oracle_vectors.npz     outputs of the CPU oracle (oracle/ref_model.py, the same torch.nn modules the
+                         reference instantiates) on synthetic checkpoints from vit_amd.synth (numpy PCG64,
+                         identical on every box): eval logits, train-mode loss, per-parameter gradient
+                         L2 norms, and the logits of the 11 images
+
+The reference itself cannot be imported (timm / torchvision absent: ModuleNotFoundError), so these
+pin the ORACLE across machines and torch builds; they are not outputs of the reference's code.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.ref_model import CNNViTHybridRef  # noqa: E402
+from vit_amd.infer import preprocess  # noqa: E402
+from vit_amd.synth import CLASSES, micro_doppler_batch, synth_state_dict  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SPLIT = "/root/reference/splits/test"
+
+CONFIGS = {
+    "tiny": (dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=2, dropout=0.0, backbone="patch16"), 2, 11),
+    "R": (dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.0, backbone="resnet18"), 2, 0),
+    "legacy": (dict(num_classes=11, embed_dim=384, num_heads=6, num_layers=6, dropout=0.0, backbone="resnet18"), 1, 1),
+}
+
+
+def main():
+    torch.set_num_threads(8)
+    os.makedirs(os.path.join(GOLD, "images"), exist_ok=True)
+    manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "images": {}}
+    imgs = []
+    for cls in CLASSES:
+        d = os.path.join(SPLIT, cls)
+        f = sorted(os.listdir(d))[0]
+        g = Image.open(os.path.join(d, f)).convert("L").resize((224, 224), Image.BILINEAR)
+        g.save(os.path.join(GOLD, "images", cls + ".png"), optimize=True)
+        manifest["images"][cls] = f
+        imgs.append(preprocess(Image.open(os.path.join(GOLD, "images", cls + ".png"))))
+    ximg = torch.stack(imgs)
+    out = {}
+    for name, (cfg, B, seed) in CONFIGS.items():
+        ref = CNNViTHybridRef(**cfg)
+        sd = synth_state_dict({k: v.shape for k, v in ref.state_dict().items()}, seed)
+        ref.load_state_dict(sd)
+        x = micro_doppler_batch(B, seed=100 + seed)
+        y = torch.arange(B) % 11
+        ref.eval()
+        with torch.no_grad():
+            out[f"{name}/logits_eval"] = ref(x).numpy()
+            if name == "R":
+                out["R/image_logits"] = ref(ximg).numpy()
+        ref.train()
+        loss = F.cross_entropy(ref(x), y, label_smoothing=0.05)
+        loss.backward()
+        out[f"{name}/loss_train"] = np.float32(loss.item())
+        names = [n for n, _ in ref.named_parameters()]
+        out[f"{name}/grad_norms"] = np.array([p.grad.norm().item() for _, p in ref.named_parameters()], np.float32)
+        manifest[f"{name}/param_names"] = names
+        manifest[f"{name}/config"] = cfg
+        manifest[f"{name}/batch"] = B
+        manifest[f"{name}/seed"] = seed
+    np.savez_compressed(os.path.join(GOLD, "oracle_vectors.npz"), **out)
+    with open(os.path.join(GOLD, "manifest.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1)
+    print({k: getattr(v, "shape", v) for k, v in out.items()})
+    print("image argmax:", [CLASSES[i] for i in out["R/image_logits"].argmax(1)])
+    srt = np.sort(out["R/image_logits"], axis=1)
+    print("image top-1 margins:", np.round(srt[:, -1] - srt[:, -2], 2))
+
+
+if __name__ == "__main__":
+    main()

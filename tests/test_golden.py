@@ -1,0 +1,93 @@
+"""CPU: the oracle against the committed golden vectors (tests/golden/, made by scripts/make_golden.py
+in the build container), and the torchvision-free preprocessing / post-processing restatement.
+The vectors pin the oracle across machines and torch builds; no reference-side fixture exists for
+this path ("parity unpinned" at the timm boundary)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(GOLD, "manifest.json")) as fh:
+        man = json.load(fh)
+    return man, np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+
+
+@pytest.mark.parametrize("name", ["tiny", "R", "legacy"])
+def test_oracle_reproduces_golden_vectors(gold, name):
+    from oracle.ref_model import CNNViTHybridRef
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    man, vec = gold
+    cfg, B, seed = man[f"{name}/config"], man[f"{name}/batch"], man[f"{name}/seed"]
+    ref = CNNViTHybridRef(**cfg)
+    ref.load_state_dict(synth_state_dict({k: v.shape for k, v in ref.state_dict().items()}, seed))
+    x = micro_doppler_batch(B, seed=100 + seed)
+    ref.eval()
+    with torch.no_grad():
+        logits = ref(x).numpy()
+    assert np.allclose(logits, vec[f"{name}/logits_eval"], rtol=1e-3, atol=2e-3)
+    ref.train()
+    loss = F.cross_entropy(ref(x), torch.arange(B) % 11, label_smoothing=0.05)
+    loss.backward()
+    assert abs(loss.item() - float(vec[f"{name}/loss_train"])) < 2e-3
+    assert [n for n, _ in ref.named_parameters()] == man[f"{name}/param_names"]
+    norms = np.array([p.grad.norm().item() for _, p in ref.named_parameters()], np.float32)
+    assert np.allclose(norms, vec[f"{name}/grad_norms"], rtol=5e-3, atol=1e-5)
+
+
+def test_golden_images_and_preprocessing(gold):
+    from PIL import Image
+    from vit_amd.infer import preprocess
+    from vit_amd.synth import CLASSES
+    man, vec = gold
+    assert sorted(man["images"]) == sorted(CLASSES)
+    for cls in CLASSES:
+        img = Image.open(os.path.join(GOLD, "images", cls + ".png"))
+        assert img.size == (224, 224) and img.mode == "L"
+        x = preprocess(img)
+        assert x.shape == (3, 224, 224) and x.dtype == torch.float32
+        a = np.asarray(img, dtype=np.float32) / 255.0
+        # the three channels are the same luma, normalised with the ImageNet statistics (infer.py:349-352)
+        for c, (m, s) in enumerate(zip((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))):
+            assert np.allclose(x[c].numpy(), (a - m) / s, atol=1e-6)
+    # an RGB image of another size goes through luma + bilinear resize
+    rgb = Image.fromarray((np.random.default_rng(0).random((80, 120, 3)) * 255).astype(np.uint8))
+    assert preprocess(rgb).shape == (3, 224, 224)
+
+
+def test_postprocess_topk(gold):
+    from vit_amd.infer import postprocess
+    from vit_amd.synth import CLASSES
+    man, vec = gold
+    logits = torch.from_numpy(vec["R/image_logits"])
+    res = postprocess(logits, CLASSES, confidence_threshold=0.5, top_k=3)
+    probs = torch.softmax(logits, dim=1)
+    for r, pr in zip(res, probs):
+        assert r.prediction == CLASSES[int(pr.argmax())]
+        assert abs(r.confidence - float(pr.max())) < 1e-6
+        assert len(r.top_k) == 3 and r.top_k[0][0] == r.prediction
+        assert r.is_reliable == (r.confidence >= 0.5)
+        assert r.raw_logits.shape == (1, 11)
+
+
+def test_load_model_errors(tmp_path):
+    from vit_amd.infer import load_model, validate_input
+    with pytest.raises(FileNotFoundError):
+        load_model(str(tmp_path / "missing.pt"), torch.device("cpu"))
+    ok, msg = validate_input(str(tmp_path / "missing.png"))
+    assert not ok and "not found" in msg
+    bad = tmp_path / "x.txt"
+    bad.write_text("hi")
+    ok, msg = validate_input(str(bad))
+    assert not ok and "Invalid file type" in msg
+    corrupt = tmp_path / "c.png"
+    corrupt.write_bytes(b"not a png")
+    ok, msg = validate_input(str(corrupt))
+    assert not ok and "Corrupted" in msg

@@ -1,0 +1,78 @@
+"""GPU: the HIP path against the committed golden vectors and on the 11 real spectrograms
+(BASELINE.json configs[0] plumbing: image file -> label), through the reference-shaped caller API
+(vit_amd/infer.py).  Tolerance: |logit - golden| <= 0.15 + 0.05*|golden| (bf16 compute vs the fp32
+oracle, the bound of tests/test_model_gpu.py); argmax must agree wherever the golden top-1 margin
+exceeds twice that bound."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ATOL, RTOL = 0.15, 0.05
+
+
+def _gold():
+    with open(os.path.join(GOLD, "manifest.json")) as fh:
+        man = json.load(fh)
+    return man, np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+
+
+def _model(cfg, seed, dev):
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.synth import synth_state_dict
+    m = CNNViTHybrid(**cfg)
+    m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, seed))
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", ["tiny", "R", "legacy"])
+def test_hip_logits_match_golden(dev, name):
+    from vit_amd.synth import micro_doppler_batch
+    man, vec = _gold()
+    cfg, B, seed = man[f"{name}/config"], man[f"{name}/batch"], man[f"{name}/seed"]
+    m = _model(cfg, seed, dev)
+    with torch.no_grad():
+        logits = m(micro_doppler_batch(B, seed=100 + seed).to(dev)).cpu().numpy()
+    ref = vec[f"{name}/logits_eval"]
+    err = np.abs(logits - ref)
+    print(f"\n[{name}] max |err| {err.max():.4f}")
+    assert (err <= ATOL + RTOL * np.abs(ref)).all()
+
+
+def test_real_images_to_labels(dev, tmp_path):
+    from PIL import Image
+    from vit_amd.infer import load_model, predict_batch, predict_folder, predict_single
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.synth import CLASSES, synth_checkpoint
+    man, vec = _gold()
+    cfg = man["R/config"]
+    # a synthetic checkpoint in the reference layout, written and re-read through load_model
+    ck = synth_checkpoint(CNNViTHybrid(**cfg), seed=man["R/seed"])
+    path = tmp_path / "cnn_vit_radar.pt"
+    torch.save(ck, path)
+    model, classes, meta = load_model(str(path), dev)
+    assert classes == CLASSES and meta["mode"] == "single" and not model.training
+    imgs = [Image.open(os.path.join(GOLD, "images", c + ".png")) for c in CLASSES]
+    res = predict_batch(model, imgs, classes, dev, top_k=3)
+    ref = vec["R/image_logits"]
+    got = np.concatenate([r.raw_logits for r in res])
+    bound = ATOL + RTOL * np.abs(ref)
+    assert (np.abs(got - ref) <= bound).all(), np.abs(got - ref).max()
+    srt = np.sort(ref, axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    for i, r in enumerate(res):
+        if margin[i] > 2 * bound[i].max():
+            assert r.prediction == CLASSES[int(ref[i].argmax())]
+        assert 0.0 < r.confidence <= 1.0 and len(r.top_k) == 3
+    # file-based entry points (infer.py:356-430) agree with the batched call
+    one = predict_single(model, os.path.join(GOLD, "images", "Away.png"), classes, dev)
+    assert one is not None and np.allclose(one.raw_logits, res[0].raw_logits, atol=0.05)
+    assert predict_single(model, str(tmp_path / "nope.png"), classes, dev) is None
+    folder = predict_folder(model, os.path.join(GOLD, "images"), classes, dev)
+    assert sorted(folder) == sorted(c + ".png" for c in CLASSES)
+    for c, r in zip(CLASSES, res):
+        assert folder[c + ".png"].prediction == r.prediction
