@@ -46,20 +46,27 @@ __device__ __forceinline__ int fdiv(int m, int d, float inv_d) {
 constexpr int TM = 64;             // M rows per staged tile
 constexpr int TILE_B = TM * 256;   // bytes of one operand tile (64 rows x 128 bf16)
 
-template <bool GATHER>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p) {
+// NARROW (N <= 64, the 64-channel stem layers): only the first 64 columns of the dY tile are real, so
+// instead of idling two waves on zero rows the wave pairs split the 64-row M tile in halves (32 rows
+// each) over the same 64(n) x 128(k) output; the atomics of the epilogue add the two halves.
+template <bool GATHER, bool NARROW>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p, int ntiles, int nsplits) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (dY tile + X tile)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wn = wave >> 1, wk = wave & 1;  // wave's 64x64 quadrant of the 128x128 output tile
+  const int wn = NARROW ? 0 : wave >> 1, wk = wave & 1;  // wave's 64x64 quadrant of the 128x128 output tile
 
+  // workgroup -> (output tile, M split), tiles fastest.  (Pinning a split's tiles to one XCD so its L2
+  // serves their re-reads was measured and is 5-15 % SLOWER on the stem shapes: profiles/r01_wgrad_splits.txt.)
+  const int tile_id = blockIdx.x % ntiles;
+  const int split = blockIdx.x / ntiles;
   const int ntk = (p.K + 127) / 128;
-  const int tile_n = blockIdx.x / ntk, tile_k = blockIdx.x - tile_n * ntk;
+  const int tile_n = tile_id / ntk, tile_k = tile_id - tile_n * ntk;
   const int n0 = tile_n * 128, k0 = tile_k * 128;
 
   // M range of this split, in 64-row tiles
   const long mtiles = (p.M + TM - 1) / TM;
-  const long per = (mtiles + gridDim.y - 1) / gridDim.y;
-  const long mt_begin = (long)blockIdx.y * per;
+  const long per = (mtiles + nsplits - 1) / nsplits;
+  const long mt_begin = (long)split * per;
   long mt_end = mt_begin + per;
   if (mt_end > mtiles) mt_end = mtiles;
   const int nmt = (int)(mt_end - mt_begin);
@@ -149,7 +156,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p) {
     const char* sY = smem + stage * (2 * TILE_B);
     const char* sX = sY + TILE_B;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks0 = 0; ks0 < (NARROW ? 1 : 2); ++ks0) {
+      const int ks = NARROW ? (wave >> 1) : ks0;
       bf16x8 yf[4], xf[4];
       const int rbase = (ks * 32 + rd_row) * 256 + rd_byte;
 #pragma unroll
@@ -224,16 +232,25 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
   if (a.M == 0) return RVIT_OK;
   const long tiles = (long)((a.N + 127) / 128) * ((a.K + 127) / 128);
   const long mtiles = (a.M + TM - 1) / TM;
-  long splits = a.splits > 0 ? a.splits : (1024 + tiles - 1) / tiles;  // ~4 workgroups per CU
+  // ~1024 workgroups (two fit a CU at 64 KB LDS each; two rounds measured best on the stem shapes,
+  // profiles/r01_wgrad_splits.txt).  Every split adds N*K atomics, so a split must also own a few M
+  // tiles to pay for its epilogue (the encoder Linears: M = B*S is short).
+  const long target = a.mode == 1 ? 1024 : 512;
+  long splits = a.splits > 0 ? a.splits : (target + tiles - 1) / tiles;
+  if (a.splits <= 0 && splits > (mtiles + 3) / 4) splits = (mtiles + 3) / 4;
   if (splits > mtiles) splits = mtiles;
-  if (splits > 65535) splits = 65535;
   if (splits < 1) splits = 1;
+  RVIT_CHECK_ARG(tiles * splits < 0x7fffffffL, "wgrad: too many workgroups");
   const size_t lds = 2 * 2 * TILE_B;  // 64 KB
-  dim3 grid((unsigned)tiles, (unsigned)splits);
-  if (a.mode == 1)
-    hipLaunchKernelGGL(wgrad_bf16_kernel<true>, grid, dim3(256), lds, st, a);
-  else
-    hipLaunchKernelGGL(wgrad_bf16_kernel<false>, grid, dim3(256), lds, st, a);
+  dim3 grid((unsigned)(tiles * splits));
+  const bool narrow = a.N <= 64;
+  if (a.mode == 1) {
+    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+  } else {
+    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+  }
   RVIT_CHECK_LAUNCH("wgrad_bf16");
   return RVIT_OK;
 }
