@@ -215,6 +215,16 @@ def main():
         del x
         train = train_leg(args, dev, dist, world, rank, sd)
 
+    if rank == 0 and roofline is not None:
+        roofline["algorithmic_bytes_per_launch"] = round(kernels[roofline["kernel"]]["bytes"] / kernels[roofline["kernel"]]["launches"])
+        # HBM traffic of the same kernel from the committed PMC passes (profiles/, same command and batch)
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as fh:
+                t = json.load(fh)
+            if t.get("kernel") == roofline["kernel"] and t.get("batch_per_gpu") == B:
+                roofline["traffic"] = t["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
     if rank == 0:
         frames = world * B * args.steps
         value = frames / dt
