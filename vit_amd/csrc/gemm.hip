@@ -415,6 +415,12 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     case 1: return launch_cfg<256, 64, 8, 1, 2>(a, stream);
     case 2: return launch_cfg<128, 64, 4, 1, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 1, 2>(a, stream);
+    case 4: return launch_cfg<256, 64, 4, 1, 2>(a, stream);  // 64x64 wave tiles (fewer LDS reads per MFMA): slower,
+    case 5: return launch_cfg<128, 64, 2, 1, 2>(a, stream);  // the loop is latency-bound and wants the 16 waves/CU
+    case 6: return launch_cfg<512, 64, 8, 1, 2>(a, stream);  // (profiles/r01_tile_sweep_wave64.txt)
+    case 4: return launch_cfg<256, 64, 4, 1, 2>(a, stream);   // 64x64 wave tiles: 0.5 LDS reads per MFMA (vs 0.75)
+    case 5: return launch_cfg<128, 64, 2, 1, 2>(a, stream);
+    case 6: return launch_cfg<512, 64, 8, 1, 2>(a, stream);
     default: rvit_set_error("gemm: unknown tile config %d", cfg); return RVIT_EINVAL;
   }
 }
