@@ -263,3 +263,56 @@ def test_errors_are_loud(dev):
         ops.gemm(a, w, out)
     with pytest.raises(RuntimeError):
         ops.gemm(a.cpu(), w.cpu(), out.cpu())
+
+
+@pytest.mark.parametrize("cin,cout,hw,B", [(64, 64, 56, 2), (128, 128, 28, 3), (256, 256, 14, 5), (512, 512, 7, 11),
+                                            (64, 128, 14, 1), (128, 64, 7, 40), (128, 256, 28, 2), (384, 128, 14, 3)])
+@pytest.mark.parametrize("plain", [False, True])
+@pytest.mark.parametrize("variant", [11, 12])
+def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant):
+    """The LDS-resident 3x3/1 kernel (tile 10, csrc/conv3x3.hip) against torch and against the gather
+    kernel (tile 1): tiles that straddle image rows and image boundaries (M = B*hw*hw is not a
+    multiple of 256 for the small maps), with and without the fused epilogue, forward and flipped
+    (input-gradient) form."""
+    from vit_amd import ops
+    if variant == 12 and (cout % 128 or cin % 128):
+        pytest.skip("the 128-channel variant needs Cout (forward) and Cin (dgrad) multiples of 128")
+    g = torch.Generator().manual_seed(cin + cout + hw + B)
+    x = _bf(torch.randn(B, hw, hw, cin, generator=g))
+    w = _bf(torch.randn(cout, 3, 3, cin, generator=g) / math.sqrt(9 * cin))
+    kw = {}
+    ref = _conv_ref(x, w, 1, 1)
+    if not plain:
+        scale = torch.rand(cout, generator=g) + 0.5
+        bias = torch.randn(cout, generator=g)
+        res = _bf(torch.randn(B, hw, hw, cout, generator=g))
+        ref = torch.relu(ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res.float().permute(0, 3, 1, 2))
+        kw = dict(scale=scale.to(dev), bias=bias.to(dev), residual=res.to(dev), act="relu")
+    out = torch.empty(B, hw, hw, cout, dtype=torch.bfloat16, device=dev)
+    ops.conv2d(x.to(dev), w.reshape(cout, -1).to(dev), out, kh=3, kw=3, stride=1, pad=1, tile=variant, **kw)
+    _close(out, ref.permute(0, 2, 3, 1), 1.0 / 128, 3e-3, "direct conv")
+    out1 = torch.empty_like(out)
+    ops.conv2d(x.to(dev), w.reshape(cout, -1).to(dev), out1, kh=3, kw=3, stride=1, pad=1, tile=1, **kw)
+    # same products, different fp32 summation order: at most an ulp of bf16 apart
+    assert (out.float() - out1.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, out1.float().abs().max().item())
+    # input gradient = the same kernel on dy with flipped taps and [Cin, kh, kw, Cout] weights
+    dy = _bf(torch.randn(B, hw, hw, cout, generator=g))
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    F.conv2d(xr, w.float().permute(0, 3, 1, 2), None, 1, 1).backward(dy.float().permute(0, 3, 1, 2))
+    w_t = w.permute(3, 1, 2, 0).reshape(cin, 9 * cout).contiguous()
+    dx = torch.empty(B, hw, hw, cin, dtype=torch.bfloat16, device=dev)
+    resx = None if plain else _bf(torch.randn(B, hw, hw, cin, generator=g))
+    ops.conv2d_dgrad(dy.to(dev), w_t.to(dev), dx, kh=3, kw=3, stride=1, pad=1, tile=variant,
+                     residual=None if plain else resx.to(dev))
+    want = xr.grad.permute(0, 2, 3, 1) + (0 if plain else resx.float())
+    _close(dx, want, 1.0 / 128, 2e-2, "direct dgrad")
+
+
+def test_conv3x3_direct_rejects_other_geometry(dev):
+    from vit_amd import ops
+    from vit_amd._lib import RvitError
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(64, 9 * 64, dtype=torch.bfloat16, device=dev)
+    y = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RvitError):
+        ops.conv2d(x, w, y, kh=3, kw=3, stride=2, pad=1, tile=10)

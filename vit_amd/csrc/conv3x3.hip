@@ -1,0 +1,352 @@
+// Direct 3x3 / stride 1 / pad 1 NHWC convolution on bf16 MFMA with the input patch RESIDENT in LDS.
+//
+// Replaces the 3x3 stride-1 convs of the resnet stem (13 of the 20 convs of resnet18,
+// `self.cnn_backbone(x)[-1]`, train_vit.py:87,145-146) and, with `flip`, their input gradients
+// (autograd of the same convs, train_vit.py:939).  The implicit-GEMM gather kernel (gemm.hip)
+// re-fetches every input pixel once per tap: 9 x 32 KB of L2->LDS traffic per 64 input channels of
+// a 256-pixel tile, and measured (profiles/r01_gemm_ablation.txt) that gather alone costs ~80 % of
+// the kernel time.  Here a workgroup stages, per 64-channel slice, the padded input rows its 256
+// consecutive output pixels touch ONCE (50-74 KB) and runs the nine taps out of LDS by shifting
+// the fragment row index; only the 8 KB weight tile of each tap streams through a 2-stage ring.
+//
+// Geometry.  Output pixels are numbered m = (b*H + h)*W + w; a workgroup owns BM consecutive m and
+// 64 output channels.  In "padded row" space R = b*(H+2) + h + 1 every image carries its own zero
+// rows, so tap (kh,kw) of output (R, w) reads padded pixel (R + kh - 1, w + kw) and never leaves
+// the image.  The patch holds padded rows R_first-1 .. R_last+1, all W+2 columns, 128 B (64 bf16)
+// per pixel; a pixel outside the image is DMA'd from a 16-byte zero page.  LDS row index of the
+// fragment row of output m for tap (kh,kw):  pb(m) + kh*(W+2) + kw,  pb = (R - R_first)*(W+2) + w.
+// The 16-byte chunk index inside a row is XOR-swizzled with (row>>1)&7 on the DMA source and on the
+// ds_read_b128 (same involution as gemm.hip): 16 consecutive rows read conflict-free.
+//
+// Structure: 8 waves, v_mfma_f32_16x16x32_bf16 with the weights on the A side, two variants (below);
+// epilogue identical to gemm.hip's (accumulators restaged through LDS, whole 128-byte row
+// segments to global; folded-BN scale/bias, residual, ReLU).
+#include "common.h"
+#include "rvit_internal.h"
+
+namespace {
+
+__device__ uint4 g_zero_page_c3[4];
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+constexpr int C3_BM = 256, C3_WAVES = 8;
+constexpr int C3_PIT = 10;  // patch DMA passes per wave: ceil(P_max / 8 / 8), P_max <= 640 pixels
+
+// BN = 64 : 8 waves x (32 x 64) wave tiles, one patch buffer; two workgroups per CU hide each other's
+//           patch loads.
+// BN = 128: 4 x 2 waves x (64 x 64) wave tiles (0.5 instead of 0.75 LDS fragment reads per MFMA, the
+//           patch staged once per 128 output channels) and TWO patch buffers: the next 64-channel slice
+//           streams in one 1 KB pass per wave per tap while the current one is multiplied, so one
+//           workgroup per CU (<= 152 KB) keeps the MFMA pipe busy by itself.
+// tile_len: output pixels per workgroup: 256 consecutive pixels, or (wide maps) a whole number of
+// image rows <= 256 so that the patch is (rows + 2) x (W + 2).
+template <int BN, bool DB>
+__global__ __launch_bounds__(64 * C3_WAVES, BN == 64 ? 4 : 2) void conv3x3_direct_kernel(const GemmArgs p, int patch_bytes, int tile_len) {
+  constexpr int WAVES_N = BN / 64, WAVES_M = C3_WAVES / WAVES_N;
+  constexpr int WM = C3_BM / WAVES_M, MR = WM / 16;
+  constexpr int B_LOADS = BN / 64;            // weight-tile DMA instructions per thread per tap
+  constexpr int B_STAGE = BN * 128;           // bytes of one weight tile (BN rows x 64 k)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const bring = smem + (DB ? 2 : 1) * patch_bytes;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int H = p.H, W = p.W, Cin = p.Cpix, PW = W + 2, HP = H + 2;
+  const int flip = p.transposed;
+
+  // XCD-aware tile id (as gemm.hip): n tiles of one m tile are adjacent and share an XCD's L2
+  const int ntn = p.N / BN;
+  int tid_lin;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    tid_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tid_lin / ntn, tile_n = tid_lin - tile_m * ntn;
+  const long m0 = (long)tile_m * tile_len;
+  const int n0 = tile_n * BN;
+  const int hw = H * W;
+
+  // padded-row window of this tile
+  long m_last = m0 + tile_len - 1;
+  if (m_last >= p.M) m_last = p.M - 1;
+  int R_first, R_last;
+  {
+    const int b0 = (int)(m0 / hw), r0 = (int)(m0 - (long)b0 * hw);
+    const int b1 = (int)(m_last / hw), r1 = (int)(m_last - (long)b1 * hw);
+    R_first = b0 * HP + r0 / W + 1;
+    R_last = b1 * HP + r1 / W + 1;
+  }
+  const int R0 = R_first - 1;                       // first padded row held by the patch
+  const int P = (R_last - R_first + 3) * PW;        // patch pixels (host guarantees P*128 <= patch_bytes)
+  const int npass = (P + 7) >> 3;                   // 8 pixels (1 KB) per wave-level DMA instruction
+  const int nB = (int)(p.M / hw);                   // images
+
+  // ---- per-thread patch DMA descriptors: pixel offset (in pixels) or -1 for zero fill ----------
+  const int prow_l = lane >> 3;
+  int pix[C3_PIT];
+  // source chunk = slot ^ ((row>>1)&7); row = pass*8 + prow_l and pass = wave + 8*it, so the swizzle term
+  // ((pass&1)*4 + (prow_l>>1)) & 7 is the same for every pass of this thread
+  const int pchunk = ((lane & 7) ^ ((((wave & 1) << 2) + (prow_l >> 1)) & 7)) * 8;
+#pragma unroll
+  for (int it = 0; it < C3_PIT; ++it) {
+    const int pass = wave + it * C3_WAVES;
+    const int row = pass * 8 + prow_l;              // LDS row = patch pixel index
+    pix[it] = -1;
+    if (pass < npass && row < P) {
+      const int pr = row / PW, pc = row - pr * PW;
+      const int Rp = R0 + pr;
+      const int b = Rp / HP, hh = Rp - b * HP - 1, ww = pc - 1;
+      if (b < nB && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) pix[it] = (b * H + hh) * W + ww;
+    }
+  }
+  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_page_c3);
+
+  // ---- weight-tile DMA: BN rows (n) x 8 chunks; thread -> row t>>3 (+64), chunk slot t&7 -----------
+  const int brow = t >> 3;                                        // 0..63
+  const int bchunk = ((t & 7) ^ ((brow >> 1) & 7)) * 8;           // (row+64)>>1 & 7 == row>>1 & 7
+  const bf16* b_base = p.B + (long)(n0 + brow) * p.ldb + bchunk;  // + 64*ldb for the 2nd load; + tap*Cin + c0
+  char* const b_dst = bring + wave * 1024;                        // + 8192 for the 2nd load; + stage * B_STAGE
+
+  // ---- fragment geometry ---------------------------------------------------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+  int pb[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    long m = m0 + wm * WM + i * 16 + fr;
+    if (m > m_last) m = m0;  // any in-window pixel: the result is discarded by the epilogue
+    const int b = (int)(m / hw), r = (int)(m - (long)b * hw);
+    const int h = r / W, w = r - h * W;
+    pb[i] = (b * HP + h + 1 - R_first) * PW + w;
+  }
+  const int sw_b = (fr >> 1) & 7;
+  const bool wave_live = m0 + wm * WM <= m_last;  // wave-uniform: waves past a short tile only keep the barriers
+
+  f32x4 acc[MR][4];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define ISSUE_B(step_, c0_, tapw_)                                                      \
+  do {                                                                                  \
+    char* d_ = b_dst + ((step_) & 1) * B_STAGE;                                         \
+    const bf16* s_ = b_base + (long)(tapw_) * Cin + (c0_);                              \
+    glds16(s_, d_);                                                                     \
+    if constexpr (B_LOADS == 2) glds16(s_ + 64 * p.ldb, d_ + 8192);                     \
+  } while (0)
+#define ISSUE_PATCH_PASS(it_, buf_, c0_)                                                \
+  do {                                                                                  \
+    const int pass_ = wave + (it_) * C3_WAVES;                                          \
+    const bf16* src_ = pix[it_] >= 0 ? p.A + (long)pix[it_] * Cin + (c0_) + pchunk : zero_src; \
+    glds16(src_, smem + (buf_) * patch_bytes + pass_ * 1024);                           \
+  } while (0)
+
+#define C3_TAP_BODY(tap) \
+      if (tap != 0 && pend) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); \
+      else wait_vm0(); \
+      __builtin_amdgcn_s_barrier(); \
+      if (tap < 8) { \
+        ISSUE_B(step + 1, c0, flip ? 7 - tap : tap + 1); \
+      } else if (has_next) { \
+        ISSUE_B(step + 1, c0 + 64, flip ? 8 : 0); \
+      } \
+      pend = false; \
+      if constexpr (DB) { \
+        if (has_next && wave + tap * C3_WAVES < npass) { \
+          ISSUE_PATCH_PASS(tap, cur ^ 1, c0 + 64); \
+          pend = true; \
+        } \
+      } \
+      if (wave_live) { \
+        const int roff = (tap / 3) * PW + (tap % 3); \
+        const char* sB = bring + (step & 1) * B_STAGE + wn * 8192; \
+_Pragma("unroll") \
+        for (int ks = 0; ks < 2; ++ks) { \
+          bf16x8 af[MR], bfr[4]; \
+_Pragma("unroll") \
+          for (int i = 0; i < MR; ++i) { \
+            const int row = pb[i] + roff; \
+            af[i] = *reinterpret_cast<const bf16x8*>(patch + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4)); \
+          } \
+_Pragma("unroll") \
+          for (int j = 0; j < 4; ++j) \
+            bfr[j] = *reinterpret_cast<const bf16x8*>(sB + (j * 16 + fr) * 128 + (((ks * 4 + fq) ^ sw_b) << 4)); \
+_Pragma("unroll") \
+          for (int i = 0; i < MR; ++i) \
+_Pragma("unroll") \
+            for (int j = 0; j < 4; ++j) \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0); \
+        } \
+      } \
+      ++step;
+
+  const int nchunks = Cin >> 6;
+  // prologue: the first slice's patch and the first tap's weights
+#pragma unroll
+  for (int it = 0; it < C3_PIT; ++it)
+    if (wave + it * C3_WAVES < npass) ISSUE_PATCH_PASS(it, 0, 0);
+  ISSUE_B(0, 0, flip ? 8 : 0);
+
+  int step = 0;
+  bool pend = false;  // a patch pass of the NEXT slice was issued after the latest weight tile
+  for (int c = 0; c < nchunks; ++c) {
+    const int c0 = c << 6;
+    const int cur = DB ? (c & 1) : 0;
+    const char* patch = smem + cur * patch_bytes;
+    const bool has_next = c + 1 < nchunks;
+    // weights of this tap landed; at tap 0 the whole patch slice too.  vmcnt retires in order: the one load
+    // allowed to stay in flight is the next slice's patch pass issued AFTER this tap's weights.  The
+    // barrier covers every wave; it also means every wave finished the previous tap (ring / buffer reuse).
+    // Nine taps fully unrolled only for the double-buffered variant (pix[tap] must be a register index);
+    // unrolled, the 64-channel variant would not fit the 128 VGPRs that let two workgroups share a CU.
+    if constexpr (DB) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) { C3_TAP_BODY(tap) }
+    } else {
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) { C3_TAP_BODY(tap) }
+    }
+    if constexpr (!DB) {
+      if (has_next) {
+        __builtin_amdgcn_s_barrier();  // every wave finished this slice's fragment reads: reuse the buffer
+#pragma unroll
+        for (int it = 0; it < C3_PIT; ++it)
+          if (wave + it * C3_WAVES < npass) ISSUE_PATCH_PASS(it, 0, c0 + 64);
+      }
+    }
+  }
+#undef C3_TAP_BODY
+#undef ISSUE_B
+#undef ISSUE_PATCH_PASS
+
+  // ---- epilogue (same restaging as gemm.hip): wave-private 64-column staging ----------------------
+  __builtin_amdgcn_s_barrier();
+  constexpr int EP_PITCH = 64 * 4 + 16;
+  char* ep = smem + wave * (WM * EP_PITCH);
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i][j];
+  __syncthreads();
+  const int er = lane >> 3, ec = (lane & 7) * 8;
+  const int n = n0 + wn * 64 + ec;
+  float sc[8], bi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; bi[e] = 0.f; }
+  if (p.scale) {
+    const float4 a = *reinterpret_cast<const float4*>(p.scale + n), b = *reinterpret_cast<const float4*>(p.scale + n + 4);
+    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+  }
+  if (p.bias) {
+    const float4 a = *reinterpret_cast<const float4*>(p.bias + n), b = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
+  }
+#pragma unroll
+  for (int pass = 0; pass < WM / 8; ++pass) {
+    const int row = pass * 8 + er;
+    const long m = m0 + wm * WM + row;
+    if (m > m_last) continue;
+    float v[8];
+    {
+      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4);
+      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4 + 16);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+    if (p.R) {
+      const uint4 r = *reinterpret_cast<const uint4*>((const bf16*)p.R + m * p.ldr + n);
+      v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+      v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
+    }
+    if (p.act == RVIT_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>((bf16*)p.C + m * p.ldc + n) = o;
+  }
+}
+
+}  // namespace
+
+// Rows per tile for wide maps: the largest divisor of H with rows * W <= 256 (tiles then never straddle
+// images and the patch is (rows + 2) x (W + 2)); 0 = tiles of 256 consecutive pixels.
+static int c3_tile_rows(int H, int W) {
+  if (W <= 32) return 0;
+  for (int r = C3_BM / W; r >= 1; --r)
+    if (H % r == 0) return r;
+  return 0;
+}
+// Patch pixels: padded-row window bound of a tile (see the header).
+static int c3_patch_pixels(int H, int W) {
+  const int tr = c3_tile_rows(H, W);
+  if (tr > 0) return (tr + 2) * (W + 2);
+  const int rows = (C3_BM - 1 + W - 1) / W + 2 * ((C3_BM - 1) / (H * W) + 1) + 3;
+  return rows * (W + 2);
+}
+
+bool rvit_conv3x3_direct_ok(const GemmArgs& a) {
+  if (a.mode != 1 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.seg_len != a.Cpix) return false;
+  if (a.K != 9 * a.Cpix || (a.Cpix & 63) != 0 || (a.N & 63) != 0 || a.H != a.Ho || a.W != a.Wo) return false;
+  if (!a.vec || a.gate || a.C2 || a.drop_mode || a.c_f32 || a.r_f32 || a.r_period || a.row_group) return false;
+  if (a.act == RVIT_ACT_GELU || (a.R && a.ldr != a.N) || a.ldc != a.N || a.ldb != a.K) return false;
+  const int P = c3_patch_pixels(a.H, a.W);
+  if (P > 8 * C3_WAVES * C3_PIT) return false;          // DMA pass budget (640 pixels)
+  if (a.M % ((long)a.H * a.W) != 0) return false;
+  return (long)a.M / ((long)a.H * a.W) * (a.H + 2) < 0x7fffffffL / (a.W + 2);
+}
+
+template <int BN, bool DB>
+static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream_t st) {
+  int lds = (DB ? 2 : 1) * patch_bytes + 2 * BN * 128;
+  const int ep = C3_BM * (BN / 64) * (64 * 4 + 16);   // wave-private epilogue staging, all waves
+  if (lds < ep) lds = ep;
+  static int attr_lds = 0;
+  if (lds > 65536 && lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_direct_kernel<BN, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      rvit_set_error("conv3x3: cannot raise the dynamic LDS limit to %d bytes: %s", lds, hipGetErrorString(e));
+      return RVIT_ELAUNCH;
+    }
+    attr_lds = lds;
+  }
+  const long tiles = ((a.M + tile_len - 1) / tile_len) * (long)(a.N / BN);
+  if (tiles <= 0) return RVIT_OK;
+  RVIT_CHECK_ARG(tiles < 0x7fffffffL, "conv3x3: too many tiles");
+  hipLaunchKernelGGL((conv3x3_direct_kernel<BN, DB>), dim3((unsigned)tiles), dim3(64 * C3_WAVES), lds, st, a, patch_bytes, tile_len);
+  RVIT_CHECK_LAUNCH("conv3x3_direct");
+  return RVIT_OK;
+}
+
+// variant: 0 = automatic, 1 = BN 64 (single patch buffer), 2 = BN 128 with two patch buffers
+int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
+  const int P = c3_patch_pixels(a.H, a.W);
+  const int patch_bytes = ((P + 7) / 8) * 1024;
+  const int tr = c3_tile_rows(a.H, a.W);
+  const int tile_len = tr > 0 ? tr * a.W : C3_BM;
+  // BN 128 needs N % 128 == 0, both patch buffers + 32 KB of weights in 160 KB, a patch that streams in
+  // within 9 taps (<= 72 passes), and enough tiles to fill the chip with one workgroup per CU
+  const bool wide_ok = (a.N & 127) == 0 && 2 * patch_bytes + 2 * 128 * 128 <= 160 * 1024 && (P + 7) / 8 <= 9 * C3_WAVES;
+  const long tiles128 = ((a.M + tile_len - 1) / tile_len) * (long)(a.N / 128);
+  // measured (B=512): the 128-channel variant is 15 % slower on layer2/3 and 4 % faster on layer4 than two
+  // 64-channel workgroups per CU: its 8 waves run their LDS-read and MFMA phases in lockstep between the
+  // per-tap barriers.  Kept selectable (tile 12) as the base for a staggered-wave schedule; not the default.
+  bool wide = false;
+  (void)tiles128;
+  if (variant == 2) {
+    RVIT_CHECK_ARG(wide_ok, "conv3x3: the 128-channel variant does not fit this geometry");
+    wide = true;
+  }
+  return wide ? c3_launch<128, true>(a, patch_bytes, tile_len, st) : c3_launch<64, false>(a, patch_bytes, tile_len, st);
+}

@@ -401,6 +401,18 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     RVIT_CHECK_ARG(a.G && a.ldg >= a.N, "gemm: gate operand missing");
   }
   if (a.M == 0) return RVIT_OK;
+  // 3x3 / stride 1 / pad 1 convs (and their input gradients): LDS-resident patch kernel (conv3x3.hip),
+  // at every batch size: the kernel choice must not depend on M or a sample's logits would depend on
+  // the batch it travels in (fp32 summation order differs between the two kernels);
+  // tile 10 forces it (11 / 12: its 64- / 128-channel variant), any other non-zero tile forces the gather kernel (tests compare the two)
+  if (a.tile == 0 || (a.tile >= 10 && a.tile <= 12)) {
+    const bool ok = rvit_conv3x3_direct_ok(a);
+    if (ok) return rvit_conv3x3_direct(a, a.tile >= 10 ? a.tile - 10 : 0, stream);
+    if (a.tile >= 10) {
+      rvit_set_error("conv: tile 10 (direct 3x3) does not support this geometry");
+      return RVIT_EUNSUPPORTED;
+    }
+  }
   const int forced = a.tile;
   // Measured on MI355X (profiles/r01_tile_sweep.txt): the 256x64 tile with 8 waves and two LDS
   // stages (80 KB -> 2 workgroups = 16 waves per CU) wins on every stem / encoder shape; smaller
@@ -415,12 +427,8 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     case 1: return launch_cfg<256, 64, 8, 1, 2>(a, stream);
     case 2: return launch_cfg<128, 64, 4, 1, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 1, 2>(a, stream);
-    case 4: return launch_cfg<256, 64, 4, 1, 2>(a, stream);  // 64x64 wave tiles (fewer LDS reads per MFMA): slower,
-    case 5: return launch_cfg<128, 64, 2, 1, 2>(a, stream);  // the loop is latency-bound and wants the 16 waves/CU
-    case 6: return launch_cfg<512, 64, 8, 1, 2>(a, stream);  // (profiles/r01_tile_sweep_wave64.txt)
-    case 4: return launch_cfg<256, 64, 4, 1, 2>(a, stream);   // 64x64 wave tiles: 0.5 LDS reads per MFMA (vs 0.75)
-    case 5: return launch_cfg<128, 64, 2, 1, 2>(a, stream);
-    case 6: return launch_cfg<512, 64, 8, 1, 2>(a, stream);
+    // 64x64 wave tiles (<256,64,4>, <128,64,2>, <512,64,8>: fewer LDS reads per MFMA) measured 20-35 % slower:
+    // this loop is latency-bound and wants the 16 waves per CU (profiles/r01_tile_sweep_wave64.txt)
     default: rvit_set_error("gemm: unknown tile config %d", cfg); return RVIT_EINVAL;
   }
 }
