@@ -117,6 +117,15 @@ int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extr
 int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, int splits, void* stream);
 
+/* Fused stem entry for inference: conv 7x7/2 pad 3 (3->64) + folded BatchNorm (scale, bias) + ReLU +
+ * max-pool 3x3/2 pad 1 in one kernel; the 112x112x64 map never reaches HBM.  Replaces timm resnet
+ * `conv1`/`bn1`/`act1`/`maxpool` under `self.cnn_backbone(x)[-1]` (train_vit.py:87,145-146) in eval mode.
+ *   img: bf16 [B,230,232,4] from rvit_input_pack_nhwc4 (pad_top = pad_left = 3, 224x224 image)
+ *   w:   bf16 [64,232], k = kh*32 + px*4 + ch for kh<7, px<7, ch<3, every other entry zero
+ *   scale/bias: f32 [64];  pooled: bf16 [B,56,56,64];  relu != 0 applies the ReLU. */
+int rvit_stem_conv1_pool_fwd(const void* img, const void* w, const float* scale, const float* bias, void* pooled, int B,
+                             int relu, void* stream);
+
 /* fp32 NCHW image batch -> zero-haloed bf16 NHWC4 (channel 3 = 0).  Input contract of
  * CNNViTHybrid.forward (train_vit.py:141-146: x is [B,3,224,224] float).  Writes only the
  * interior; the caller zeroes the buffer once. */

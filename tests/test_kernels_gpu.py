@@ -316,3 +316,36 @@ def test_conv3x3_direct_rejects_other_geometry(dev):
     y = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=dev)
     with pytest.raises(RvitError):
         ops.conv2d(x, w, y, kh=3, kw=3, stride=2, pad=1, tile=10)
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_stem_conv1_pool_fused(dev, B):
+    """conv7x7/2 + folded BN + ReLU + max-pool in one kernel (csrc/conv1.hip) against torch fp32 on the
+    same bf16-rounded operands and against the two-kernel path (conv2d + maxpool3x3s2)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(33 + B)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    scale = torch.rand(64, generator=g) + 0.5
+    bias = torch.randn(64, generator=g) * 0.3
+    xp = torch.zeros(B, 230, 232, 4, dtype=torch.bfloat16, device=dev)
+    ops.input_pack(x.to(dev), xp, 3, 3)
+    wp = torch.zeros(64, 7, 8, 4)
+    wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wp = _bf(wp).reshape(64, 224)
+    w232 = torch.zeros(64, 232, dtype=torch.bfloat16)
+    w232[:, :224] = wp
+    pooled = torch.empty(B, 56, 56, 64, dtype=torch.bfloat16, device=dev)
+    ops.stem_conv1_pool(xp, w232.to(dev), scale.to(dev), bias.to(dev), pooled)
+    conv = F.conv2d(_bf(x).float(), _bf(w).float(), None, 2, 3) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    ref = F.max_pool2d(_bf(torch.relu(conv)).float(), 3, 2, 1).permute(0, 2, 3, 1)
+    _close(pooled, ref, 1.0 / 128, 3e-3, "fused stem")
+    # two-kernel path: same products in the same order -> identical up to (rare) rounding ties
+    y = torch.empty(B, 112, 112, 64, dtype=torch.bfloat16, device=dev)
+    ops.conv2d(xp, wp.to(dev), y, kh=7, kw=1, stride=2, pad=0, seg_len=32, scale=scale.to(dev), bias=bias.to(dev),
+               act="relu")
+    p2 = torch.empty_like(pooled)
+    ops.maxpool3x3s2(y, p2)
+    diff = (pooled.float() - p2.float()).abs()
+    assert (diff > 0).float().mean().item() < 1e-3
+    assert diff.max().item() <= 2.0 ** -7 * max(1.0, p2.float().abs().max().item())

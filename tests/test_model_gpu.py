@@ -123,9 +123,13 @@ def test_stages_teacher_forced_against_bf16_emulation(dev):
     with torch.no_grad():
         ops.input_pack(x.to(dev), b["img"], 3, 3)
         c1 = P["conv1"]
-        ops.conv2d(b["img"], c1["w"], b["c1"], kh=7, kw=1, stride=2, pad=0, seg_len=32, scale=c1["scale"],
+        y1 = torch.empty(B, 112, 112, 64, dtype=torch.bfloat16, device=dev)
+        ops.conv2d(b["img"], c1["w"], y1, kh=7, kw=1, stride=2, pad=0, seg_len=32, scale=c1["scale"],
                    bias=c1["bias"], act="relu")
-        _ulp_check("conv1+bn+relu", b["c1"].permute(0, 3, 1, 2), taps["c1"], 1e-3)
+        _ulp_check("conv1+bn+relu", y1.permute(0, 3, 1, 2), taps["c1"], 1e-3)
+        # the fused stem entry the engine actually runs (conv1 + BN + ReLU + max-pool in one kernel)
+        ops.stem_conv1_pool(b["img"], c1["w232"], c1["scale"], c1["bias"], b["s1a"])
+        _ulp_check("conv1+bn+relu+pool (fused)", b["s1a"].permute(0, 3, 1, 2), taps["pool"], 1e-3)
         # every BasicBlock, teacher-forced with the emulation's block input
         prev = "pool"
         names = [f"l{li}.{bi}" for li in range(1, 5) for bi in range(2)]

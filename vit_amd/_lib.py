@@ -40,6 +40,7 @@ SIGNATURES = {
     "rvit_conv2d_tokens_fwd": ([P, P, P] + [I] * 12 + [P, P, F, U64, I, P], c_int),
     "rvit_wgrad_bf16": ([P, L, I, I, P, L, I, I, P, L, L, I, I, I, I, P], c_int),
     "rvit_conv2d_wgrad_bf16": ([P, P, P] + [I] * 12 + [I, P], c_int),
+    "rvit_stem_conv1_pool_fwd": ([P, P, P, P, P, I, I, P], c_int),
     "rvit_input_pack_nhwc4": ([P, P] + [I] * 8 + [P], c_int),
     "rvit_maxpool3x3s2_nhwc": ([P, P, P] + [I] * 4 + [P], c_int),
     "rvit_embed_cls": ([P, P, P, I, I, I, F, U64, P], c_int),

@@ -159,6 +159,11 @@ int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int 
   return rvit_wgrad_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_stem_conv1_pool_fwd(const void* img, const void* w, const float* scale, const float* bias, void* pooled, int B,
+                             int relu, void* stream) {
+  return rvit_stem_conv1_pool_impl(img, w, scale, bias, pooled, B, relu, (hipStream_t)stream);
+}
+
 int rvit_input_pack_nhwc4(const float* x_nchw, void* out, int B, int C, int H, int W, int Hp, int Wp, int pad_top,
                           int pad_left, void* stream) {
   return rvit_input_pack_impl(x_nchw, out, B, C, H, W, Hp, Wp, pad_top, pad_left, (hipStream_t)stream);

@@ -1,0 +1,191 @@
+// Stem entry of the resnet feature extractor, fused for inference:
+//   conv 7x7 / stride 2 / pad 3 (3 -> 64) + folded BatchNorm + ReLU + max-pool 3x3 / stride 2 / pad 1
+// (timm resnet18 `conv1`, `bn1`, `act1`, `maxpool` under `self.cnn_backbone(x)[-1]`,
+// train_vit.py:87,145-146).  As two kernels the 112x112x64 map costs 1.6 MB of HBM writes plus
+// 1.6 MB of reads per sample and is the largest single item of the inference step
+// (profiles/r01_rocprof_summary.txt: conv1 662 us + max-pool 237 us of 4.2 ms at B = 512).  Fused,
+// the map never leaves the CU: HBM sees the packed image (427 KB/sample) and the pooled map
+// (401 KB/sample).
+//
+// A workgroup produces TP = 2 pooled rows of one image.  They need conv rows 2*py0-1 .. 2*py0+3
+// (5 rows, one shared with the neighbouring band: 25 % recompute of a conv that is 6 % of the
+// network) which need 15 rows of the zero-haloed NHWC4 image (rvit_input_pack_nhwc4: [B,230,232,4],
+// 8 B per pixel) = ONE contiguous 27.8 KB block, DMA'd straight into LDS together with the 29 KB of
+// weights.  In NHWC4 the 7 taps x 3 channels of one kernel row are one contiguous 64-byte run
+// (8 px x 4 ch), so an MFMA B-fragment of output pixel c, kernel row kh is the 16 bytes at
+//   patch[(2*r + kh) * 232 + 2*c] + 16*fq
+// read in place: no im2col, no swizzle (16 consecutive pixels -> 16 consecutive 16-byte slots).
+// Weights: [64, 232] bf16, k = kh*32 + px*4 + ch (7 x 32 used, row pitch 464 B keeps the
+// ds_read_b128 of 16 rows conflict-free).  v_mfma_f32_16x16x32_bf16, K = 7 steps of 32.
+// Conv outputs go through scale/bias/ReLU into an LDS map (144 B per pixel, conflict-free 8-byte
+// writes) that aliases the dead patch and weights; the pool phase reads 3x3 windows from it and
+// writes whole 128-byte pixels.  80.6 KB LDS -> two workgroups per CU overlap load / MFMA / pool.
+#include "common.h"
+#include "rvit_internal.h"
+
+namespace {
+
+__device__ uint4 g_zero_page_c1[4];
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+__device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+constexpr int HP = 230, WP = 232;          // packed image rows / cols (halo 3 top/left, 3 / 5 bottom/right)
+constexpr int WC = 112;                    // conv output is 112 x 112
+constexpr int HQ = 56, WQ = 56;            // pooled output
+constexpr int TP = 2;                      // pooled rows per workgroup
+constexpr int NCR = 2 * TP + 1;            // conv rows per workgroup
+constexpr int ROW_B = WP * 8;              // 1856 bytes per packed row
+constexpr int W_PITCH = 464;               // weight row pitch in LDS and in the packed tensor (232 bf16)
+constexpr int W_BYTES = 64 * W_PITCH;      // 29696 = 29 KB
+constexpr int PATCH_BYTES = 28 * 1024;     // 15 rows = 27840 B, rounded to whole 1 KB DMA instructions
+constexpr int CO_PITCH = 144;              // conv-out LDS pitch per pixel
+constexpr int CO_BYTES = NCR * WC * CO_PITCH;  // 80640
+constexpr int NBLK = NCR * (WC / 16);      // 35 blocks of 16 pixels
+constexpr int BLK_PER_WAVE = (NBLK + 7) / 8;   // 5
+
+__global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const bf16* __restrict__ img, const bf16* __restrict__ w,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ bias, bf16* __restrict__ pooled,
+                                                            int relu) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sW = smem;
+  char* const sP = smem + W_BYTES;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int band = blockIdx.x % (HQ / TP), b = blockIdx.x / (HQ / TP);
+  const int py0 = band * TP;
+  const int cr0 = 2 * py0 - 1;                    // first conv row of the band (-1 for the top band: skipped)
+  const int prow0 = cr0 < 0 ? 0 : 2 * cr0;        // first packed row held by the patch
+  const int prow1 = 2 * (cr0 + NCR - 1) + 6;      // last packed row needed (<= 228)
+  const int pbytes = (prow1 - prow0 + 1) * ROW_B;
+  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_page_c1);
+
+  // ---- stage weights (29 x 1 KB) and the image patch (<= 28 x 1 KB), both contiguous copies ---------
+  for (int i = wave; i < W_BYTES / 1024; i += 8) glds16(reinterpret_cast<const char*>(w) + i * 1024 + lane * 16, sW + i * 1024);
+  {
+    const char* src = reinterpret_cast<const char*>(img) + ((long)b * HP + prow0) * ROW_B;
+    for (int i = wave; i < PATCH_BYTES / 1024; i += 8) {
+      const int off = i * 1024 + lane * 16;
+      glds16(off < pbytes ? (const void*)(src + off) : (const void*)zero_src, sP + i * 1024);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- MFMA: each wave owns up to 5 blocks of 16 pixels x 64 channels ----------------------------------
+  const int fr = lane & 15, fq = lane >> 4;
+  f32x4 acc[BLK_PER_WAVE][4];
+  int a_off[BLK_PER_WAVE];
+  bool live[BLK_PER_WAVE];
+#pragma unroll
+  for (int q = 0; q < BLK_PER_WAVE; ++q) {
+    const int blk = wave + 8 * q;
+    const int lr = blk / 7, cb = blk - lr * 7;
+    live[q] = blk < NBLK && cr0 + lr >= 0;          // wave-uniform
+    a_off[q] = ((2 * (cr0 + lr) - prow0) * WP + 2 * (cb * 16 + fr)) * 8 + fq * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll 1
+  for (int kh = 0; kh < 7; ++kh) {
+    bf16x8 bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bfr[j] = *reinterpret_cast<const bf16x8*>(sW + (j * 16 + fr) * W_PITCH + kh * 64 + fq * 16);
+#pragma unroll
+    for (int q = 0; q < BLK_PER_WAVE; ++q) {
+      if (!live[q]) continue;
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(sP + a_off[q] + kh * ROW_B);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[q][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // patch and weights are dead: the conv-out map aliases them
+
+  // ---- scale / bias / ReLU -> bf16 conv-out map in LDS ([NCR][112] pixels, 144 B pitch) -----------------
+  // lane holds channels 16j + 4fq + (0..3) of pixel fr of each of its blocks
+  float sc[4][4], bi[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 s4 = *reinterpret_cast<const float4*>(scale + 16 * j + 4 * fq);
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + 16 * j + 4 * fq);
+    sc[j][0] = s4.x; sc[j][1] = s4.y; sc[j][2] = s4.z; sc[j][3] = s4.w;
+    bi[j][0] = b4.x; bi[j][1] = b4.y; bi[j][2] = b4.z; bi[j][3] = b4.w;
+  }
+#pragma unroll
+  for (int q = 0; q < BLK_PER_WAVE; ++q) {
+    if (!live[q]) continue;
+    const int blk = wave + 8 * q;
+    char* dst = smem + (blk * 16 + fr) * CO_PITCH + fq * 8;   // blk*16 = lr*112 + cb*16
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[q][j][r] * sc[j][r] + bi[j][r];
+        if (relu) v[r] = fmaxf(v[r], 0.f);
+      }
+      uint2 o;
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(dst + j * 32) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- 3x3 / 2 max-pool out of LDS; one 16-byte channel chunk of one pooled pixel per thread ------------
+  for (int id = t; id < TP * WQ * 8; id += 512) {
+    const int c8 = id & 7, pp = id >> 3;
+    const int pyl = pp / WQ, px = pp - pyl * WQ;
+    float best[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) best[k] = -INFINITY;
+#pragma unroll
+    for (int dr = 0; dr < 3; ++dr) {
+      const int lr = 2 * pyl + dr;            // conv row cr0 + lr = 2*py - 1 + dr
+      if (cr0 + lr < 0) continue;
+#pragma unroll
+      for (int dc = 0; dc < 3; ++dc) {
+        const int cc = 2 * px - 1 + dc;
+        if (cc < 0) continue;
+        const uint4 u = *reinterpret_cast<const uint4*>(smem + (lr * WC + cc) * CO_PITCH + c8 * 16);
+        best[0] = fmaxf(best[0], bf16_lo(u.x)); best[1] = fmaxf(best[1], bf16_hi(u.x));
+        best[2] = fmaxf(best[2], bf16_lo(u.y)); best[3] = fmaxf(best[3], bf16_hi(u.y));
+        best[4] = fmaxf(best[4], bf16_lo(u.z)); best[5] = fmaxf(best[5], bf16_hi(u.z));
+        best[6] = fmaxf(best[6], bf16_lo(u.w)); best[7] = fmaxf(best[7], bf16_hi(u.w));
+      }
+    }
+    uint4 o;  // the values are bf16 already: packing is exact
+    o.x = pack_bf16x2(best[0], best[1]); o.y = pack_bf16x2(best[2], best[3]);
+    o.z = pack_bf16x2(best[4], best[5]); o.w = pack_bf16x2(best[6], best[7]);
+    *reinterpret_cast<uint4*>(pooled + (((long)b * HQ + py0 + pyl) * WQ + px) * 64 + c8 * 8) = o;
+  }
+}
+
+}  // namespace
+
+int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
+                              int B, int relu, hipStream_t st) {
+  RVIT_CHECK_ARG(img && w && scale && bias && pooled && B > 0, "stem_conv1_pool: bad arguments");
+  RVIT_CHECK_ARG(rvit_aligned16(img) && rvit_aligned16(w) && rvit_aligned16(scale) && rvit_aligned16(bias) &&
+                     rvit_aligned16(pooled),
+                 "stem_conv1_pool: operands must be 16-byte aligned");
+  RVIT_CHECK_ARG((long)B * (HQ / TP) < 0x7fffffffL, "stem_conv1_pool: batch too large");
+  static_assert(CO_BYTES >= W_BYTES + PATCH_BYTES, "conv-out map must cover the staging area it aliases");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv1_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CO_BYTES);
+    if (e != hipSuccess) {
+      rvit_set_error("stem_conv1_pool: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      return RVIT_ELAUNCH;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL(conv1_pool_kernel, dim3((unsigned)(B * (HQ / TP))), dim3(512), CO_BYTES, st, (const bf16*)img,
+                     (const bf16*)w, scale, bias, (bf16*)pooled, relu);
+  RVIT_CHECK_LAUNCH("stem_conv1_pool");
+  return RVIT_OK;
+}

@@ -69,7 +69,10 @@ class Engine:
         if m.cnn_backbone is not None:
             cb = m.cnn_backbone
             s, b = _bn_fold(cb.bn1)
-            P["conv1"] = dict(w=_pack_conv_px4(cb.conv1.weight, 8), scale=s, bias=b)
+            w1 = _pack_conv_px4(cb.conv1.weight, 8)                       # [64, 7*32]
+            w1p = torch.zeros(64, 232, dtype=BF16, device=dev)             # row pitch of the fused stem kernel
+            w1p[:, :224] = w1
+            P["conv1"] = dict(w=w1, w232=w1p, scale=s, bias=b)
             blocks = []
             for blk in cb.blocks():
                 d = {}
@@ -124,7 +127,6 @@ class Engine:
         b: Dict[str, torch.Tensor] = {}
         if m.cnn_backbone is not None:
             b["img"] = torch.zeros(B, 230, 232, 4, **z)  # halo stays zero forever
-            b["c1"] = torch.empty(B, 112, 112, 64, **z)
             hw = 56
             for li, c in enumerate((64, 128, 256, 512), start=1):
                 for nm in ("a", "b", "c", "d"):
@@ -145,9 +147,8 @@ class Engine:
     # ---- forward -------------------------------------------------------------------------------
     def _stem(self, P, b, B) -> torch.Tensor:
         c1 = P["conv1"]
-        ops.conv2d(b["img"], c1["w"], b["c1"], kh=7, kw=1, stride=2, pad=0, seg_len=32, scale=c1["scale"],
-                   bias=c1["bias"], act="relu")
-        cur = ops.maxpool3x3s2(b["c1"], b["s1a"])
+        # conv7x7/2 + folded BN + ReLU + max-pool in one kernel: the 112x112x64 map stays on chip
+        cur = ops.stem_conv1_pool(b["img"], c1["w232"], c1["scale"], c1["bias"], b["s1a"])
         stage, free = 1, ["b", "c", "d"]
         for blk in P["blocks"]:
             stride = blk["c1"]["stride"]

@@ -212,6 +212,24 @@ def conv2d_tokens(x: torch.Tensor, w: torch.Tensor, tokens: torch.Tensor, pos_em
     return tokens
 
 
+def stem_conv1_pool(img: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, pooled: torch.Tensor,
+                    relu: bool = True) -> torch.Tensor:
+    """conv7x7/2 + folded BN + ReLU + maxpool3x3/2 fused: img bf16 [B,230,232,4] -> pooled bf16 [B,56,56,64]."""
+    _need_cuda(img, w, scale, bias, pooled)
+    B = img.shape[0]
+    if img.shape != (B, 230, 232, 4) or pooled.shape != (B, 56, 56, 64) or w.shape != (64, 232) \
+            or any(t.dtype != BF16 for t in (img, w, pooled)) or not (img.is_contiguous() and w.is_contiguous()
+                                                                      and pooled.is_contiguous()):
+        raise ValueError("stem_conv1_pool: img [B,230,232,4], w [64,232], pooled [B,56,56,64], all bf16 contiguous")
+    _vec_f32(scale, 64, "stem_conv1_pool: scale")
+    _vec_f32(bias, 64, "stem_conv1_pool: bias")
+    with _Span("stem_conv1_pool", 2 * B * 112 * 112 * 64 * 147, _nbytes(img, w, pooled)):
+        check(_lib.load().rvit_stem_conv1_pool_fwd(img.data_ptr(), w.data_ptr(), scale.data_ptr(), bias.data_ptr(),
+                                                   pooled.data_ptr(), B, int(relu), _stream()),
+              "rvit_stem_conv1_pool_fwd")
+    return pooled
+
+
 def input_pack(x: torch.Tensor, out: torch.Tensor, pad_top: int, pad_left: int) -> torch.Tensor:
     """x fp32 [B,C<=3,H,W] -> interior of the zero-haloed bf16 NHWC4 buffer out [B,Hp,Wp,4]."""
     _need_cuda(x, out)
