@@ -53,6 +53,11 @@ def cpu_baseline(sd, seconds=20.0, batch=8):
                       f"same weights/inputs generator"}
 
 
+def _say(rank, msg):
+    if os.environ.get("RVIT_BENCH_VERBOSE"):
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+
 def train_leg(args, dev, dist, world, rank, sd):
     """Secondary figure (BASELINE.json configs[3] shape on the R model): one optimiser step =
     forward in train() mode (BatchNorm batch statistics) + label-smoothed CE + backward on librvit +
@@ -88,13 +93,16 @@ def train_leg(args, dev, dist, world, rank, sd):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    _say(rank, "train: warm-up")
     for _ in range(3):
         step()
     sync()
+    _say(rank, "train: timed steps")
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
         loss = step()
     sync()
+    _say(rank, "train: timed steps done")
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -135,16 +143,26 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput leg")
     args = ap.parse_args()
 
+    if os.environ.get("RVIT_BENCH_VERBOSE"):  # where is every thread after 45 s?  (hang diagnosis)
+        import faulthandler
+        faulthandler.dump_traceback_later(45, exit=False)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # one process per GPU over RCCL; RVIT_BENCH_BACKEND=gloo + several ranks on one card is only a rehearsal of
+    # the multi-process code path on a 1-GPU box (scripts/rehearse_multigpu.sh), never a measurement
+    backend = os.environ.get("RVIT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from vit_amd import ops
@@ -165,10 +183,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    _say(rank, "inference: warm-up")
     with torch.no_grad():
         for _ in range(args.warmup):
             model(x)
         sync()
+        _say(rank, "inference: timed steps")
         t0 = time.perf_counter()
         for _ in range(args.steps):
             model(x)
@@ -210,6 +230,7 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": k["launches"] // min(args.steps, 5)}
 
+    _say(rank, "inference: done")
     train = None
     if not args.no_train:
         del x

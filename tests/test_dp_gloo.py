@@ -77,6 +77,17 @@ def test_grad_layout_covers_every_parameter_once():
         assert lay.names[0].startswith("head.3")
         assert lay.names[-1] == ("cnn_backbone.conv1.weight" if cfg["backbone"] != "patch16" else "patch_embed.bias")
         assert lay.param_order == [n for n, _ in m.named_parameters()]
+        if cfg["backbone"] != "patch16":
+            # the backward pass reports a stem block as final through its conv1.weight: every parameter of the
+            # block, and of every later layer, must lie at or before it in the flat buffer
+            off = {n: o for n, (o, _, _) in lay.offsets.items()}
+            blocks = sorted({n.rsplit(".", 2)[0] + "." for n in off if ".layer" in n and ".conv1.weight" in n})
+            for pref in blocks:
+                mine = [o for n, o in off.items() if n.startswith(pref)]
+                assert max(mine) == off[pref + "conv1.weight"], pref
+            order = [f"cnn_backbone.layer{li}.{bi}." for li in (4, 3, 2, 1) for bi in (1, 0)]
+            closes = [off[p + "conv1.weight"] for p in order]
+            assert closes == sorted(closes)
 
 
 def test_reducer_requires_initialised_process_group():

@@ -36,8 +36,8 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_base)
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-constexpr int C3_BM = 256, C3_WAVES = 8;
-constexpr int C3_PIT = 10;  // patch DMA passes per wave: ceil(P_max / 8 / 8), P_max <= 640 pixels
+constexpr int C3_BM = 256;
+constexpr int C3_PMAX = 640;  // patch pixels a workgroup can stage (DMA pass budget)
 
 // BN = 64 : 8 waves x (32 x 64) wave tiles, one patch buffer; two workgroups per CU hide each other's
 //           patch loads.
@@ -47,11 +47,13 @@ constexpr int C3_PIT = 10;  // patch DMA passes per wave: ceil(P_max / 8 / 8), P
 //           workgroup per CU (<= 152 KB) keeps the MFMA pipe busy by itself.
 // tile_len: output pixels per workgroup: 256 consecutive pixels, or (wide maps) a whole number of
 // image rows <= 256 so that the patch is (rows + 2) x (W + 2).
-template <int BN, bool DB>
-__global__ __launch_bounds__(64 * C3_WAVES, BN == 64 ? 4 : 2) void conv3x3_direct_kernel(const GemmArgs p, int patch_bytes, int tile_len) {
+template <int BN, bool DB, int C3_WAVES>
+__global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2) void conv3x3_direct_kernel(const GemmArgs p, int patch_bytes, int tile_len) {
   constexpr int WAVES_N = BN / 64, WAVES_M = C3_WAVES / WAVES_N;
   constexpr int WM = C3_BM / WAVES_M, MR = WM / 16;
-  constexpr int B_LOADS = BN / 64;            // weight-tile DMA instructions per thread per tap
+  constexpr int C3_PIT = C3_PMAX / 8 / C3_WAVES;  // patch DMA passes per wave
+  constexpr int B_ROWS = 8 * C3_WAVES;        // weight-tile rows covered by one DMA instruction per thread
+  constexpr int B_LOADS = BN / B_ROWS;        // weight-tile DMA instructions per thread per tap
   constexpr int B_STAGE = BN * 128;           // bytes of one weight tile (BN rows x 64 k)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const bring = smem + (DB ? 2 : 1) * patch_bytes;
@@ -109,10 +111,10 @@ __global__ __launch_bounds__(64 * C3_WAVES, BN == 64 ? 4 : 2) void conv3x3_direc
   const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_page_c3);
 
   // ---- weight-tile DMA: BN rows (n) x 8 chunks; thread -> row t>>3 (+64), chunk slot t&7 -----------
-  const int brow = t >> 3;                                        // 0..63
-  const int bchunk = ((t & 7) ^ ((brow >> 1) & 7)) * 8;           // (row+64)>>1 & 7 == row>>1 & 7
-  const bf16* b_base = p.B + (long)(n0 + brow) * p.ldb + bchunk;  // + 64*ldb for the 2nd load; + tap*Cin + c0
-  char* const b_dst = bring + wave * 1024;                        // + 8192 for the 2nd load; + stage * B_STAGE
+  const int brow = t >> 3;                                        // 0..B_ROWS-1
+  const int bchunk = ((t & 7) ^ ((brow >> 1) & 7)) * 8;           // (row + 32k)>>1 & 7 == row>>1 & 7
+  const bf16* b_base = p.B + (long)(n0 + brow) * p.ldb + bchunk;  // + l*B_ROWS*ldb for load l; + tap*Cin + c0
+  char* const b_dst = bring + wave * 1024;                        // + l*B_ROWS*128 for load l; + stage * B_STAGE
 
   // ---- fragment geometry ---------------------------------------------------------------------------
   const int fr = lane & 15, fq = lane >> 4;
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(64 * C3_WAVES, BN == 64 ? 4 : 2) void conv3x3_direc
   do {                                                                                  \
     char* d_ = b_dst + ((step_) & 1) * B_STAGE;                                         \
     const bf16* s_ = b_base + (long)(tapw_) * Cin + (c0_);                              \
-    glds16(s_, d_);                                                                     \
-    if constexpr (B_LOADS == 2) glds16(s_ + 64 * p.ldb, d_ + 8192);                     \
+    _Pragma("unroll") for (int l_ = 0; l_ < B_LOADS; ++l_)                              \
+      glds16(s_ + (long)l_ * B_ROWS * p.ldb, d_ + l_ * B_ROWS * 128);                   \
   } while (0)
 #define ISSUE_PATCH_PASS(it_, buf_, c0_)                                                \
   do {                                                                                  \
@@ -302,19 +304,19 @@ bool rvit_conv3x3_direct_ok(const GemmArgs& a) {
   if (!a.vec || a.gate || a.C2 || a.drop_mode || a.c_f32 || a.r_f32 || a.r_period || a.row_group) return false;
   if (a.act == RVIT_ACT_GELU || (a.R && a.ldr != a.N) || a.ldc != a.N || a.ldb != a.K) return false;
   const int P = c3_patch_pixels(a.H, a.W);
-  if (P > 8 * C3_WAVES * C3_PIT) return false;          // DMA pass budget (640 pixels)
+  if (P > C3_PMAX) return false;                        // DMA pass budget
   if (a.M % ((long)a.H * a.W) != 0) return false;
   return (long)a.M / ((long)a.H * a.W) * (a.H + 2) < 0x7fffffffL / (a.W + 2);
 }
 
-template <int BN, bool DB>
+template <int BN, bool DB, int C3_WAVES>
 static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream_t st) {
   int lds = (DB ? 2 : 1) * patch_bytes + 2 * BN * 128;
   const int ep = C3_BM * (BN / 64) * (64 * 4 + 16);   // wave-private epilogue staging, all waves
   if (lds < ep) lds = ep;
   static int attr_lds = 0;
   if (lds > 65536 && lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_direct_kernel<BN, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_direct_kernel<BN, DB, C3_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       rvit_set_error("conv3x3: cannot raise the dynamic LDS limit to %d bytes: %s", lds, hipGetErrorString(e));
       return RVIT_ELAUNCH;
@@ -324,12 +326,13 @@ static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream
   const long tiles = ((a.M + tile_len - 1) / tile_len) * (long)(a.N / BN);
   if (tiles <= 0) return RVIT_OK;
   RVIT_CHECK_ARG(tiles < 0x7fffffffL, "conv3x3: too many tiles");
-  hipLaunchKernelGGL((conv3x3_direct_kernel<BN, DB>), dim3((unsigned)tiles), dim3(64 * C3_WAVES), lds, st, a, patch_bytes, tile_len);
+  hipLaunchKernelGGL((conv3x3_direct_kernel<BN, DB, C3_WAVES>), dim3((unsigned)tiles), dim3(64 * C3_WAVES), lds, st, a, patch_bytes, tile_len);
   RVIT_CHECK_LAUNCH("conv3x3_direct");
   return RVIT_OK;
 }
 
-// variant: 0 = automatic, 1 = BN 64 (single patch buffer), 2 = BN 128 with two patch buffers
+// variant: 0 = automatic, 1 = BN 64 (single patch buffer), 2 = BN 128 with two patch buffers, 3 = BN 64 with
+// 4 waves of 64 x 64
 int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
   const int P = c3_patch_pixels(a.H, a.W);
   const int patch_bytes = ((P + 7) / 8) * 1024;
@@ -337,7 +340,7 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
   const int tile_len = tr > 0 ? tr * a.W : C3_BM;
   // BN 128 needs N % 128 == 0, both patch buffers + 32 KB of weights in 160 KB, a patch that streams in
   // within 9 taps (<= 72 passes), and enough tiles to fill the chip with one workgroup per CU
-  const bool wide_ok = (a.N & 127) == 0 && 2 * patch_bytes + 2 * 128 * 128 <= 160 * 1024 && (P + 7) / 8 <= 9 * C3_WAVES;
+  const bool wide_ok = (a.N & 127) == 0 && 2 * patch_bytes + 2 * 128 * 128 <= 160 * 1024 && (P + 7) / 8 <= 9 * 8;
   const long tiles128 = ((a.M + tile_len - 1) / tile_len) * (long)(a.N / 128);
   // measured (B=512): the 128-channel variant is 15 % slower on layer2/3 and 4 % faster on layer4 than two
   // 64-channel workgroups per CU: its 8 waves run their LDS-read and MFMA phases in lockstep between the
@@ -348,5 +351,6 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
     RVIT_CHECK_ARG(wide_ok, "conv3x3: the 128-channel variant does not fit this geometry");
     wide = true;
   }
-  return wide ? c3_launch<128, true>(a, patch_bytes, tile_len, st) : c3_launch<64, false>(a, patch_bytes, tile_len, st);
+  if (variant == 3) return c3_launch<64, false, 4>(a, patch_bytes, tile_len, st);
+  return wide ? c3_launch<128, true, 8>(a, patch_bytes, tile_len, st) : c3_launch<64, false, 8>(a, patch_bytes, tile_len, st);
 }

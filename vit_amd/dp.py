@@ -10,19 +10,25 @@ CPU tensors synchronously (backend "gloo", used by the CPU tests).  `finish` red
 makes the compute stream wait for the exchange.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce of b bytes costs about
-2*(7/8)*b/153 GB/s, i.e. 0.66 ms for the 58 MB of fp32 gradients of the default hybrid; 25 MB
-buckets keep each collective bandwidth- rather than latency-bound while leaving 2-3 buckets to
-overlap with the stem backward.
+2*(7/8)*b/153 GB/s, i.e. 0.66 ms for the 58 MB of fp32 gradients of the default hybrid; 8 MB
+buckets (0.09 ms each on the ring) keep each collective bandwidth- rather than latency-bound while
+the default hybrid still exchanges in 5-6 pieces: after the encoder, then after every stem block
+from layer4 down, the last one (layer1 + conv1, 0.6 MB) being all that is left exposed.
 """
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import os
+import sys
+
 import torch
+
+_VERBOSE = bool(os.environ.get("RVIT_DP_VERBOSE"))
 
 
 class BucketReducer:
-    def __init__(self, total: int, process_group=None, bucket_bytes: int = 25 << 20):
+    def __init__(self, total: int, process_group=None, bucket_bytes: int = 8 << 20):
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
@@ -37,6 +43,8 @@ class BucketReducer:
 
     def _launch(self, flat: torch.Tensor, start: int, end: int) -> None:
         chunk = flat[start:end]
+        if _VERBOSE:
+            print(f"[dp rank {self.dist.get_rank(self.group)}] all_reduce [{start}, {end})", file=sys.stderr, flush=True)
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
@@ -69,6 +77,9 @@ class BucketReducer:
             self._launch(flat, self.done, self.total)
         if flat.is_cuda and self._stream is not None:
             torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+        if _VERBOSE:
+            print(f"[dp rank {self.dist.get_rank(self.group)}] step exchanged in {len(self.buckets)} buckets",
+                  file=sys.stderr, flush=True)
         self.done = 0
 
     def begin_step(self) -> None:

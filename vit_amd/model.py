@@ -213,7 +213,7 @@ class CNNViTHybrid(nn.Module):
             object.__setattr__(self, "_train_engine", TrainEngine(self))
         return self._train_engine
 
-    def set_data_parallel(self, process_group=None, bucket_mb: float = 25.0) -> None:
+    def set_data_parallel(self, process_group=None, bucket_mb: float = 8.0) -> None:
         """Average gradients over `process_group` (RCCL) in buckets overlapped with backward."""
         self.train_engine.set_data_parallel(process_group, bucket_mb)
 

@@ -105,7 +105,7 @@ class TrainEngine:
         self.reducer = None
 
     # ---- data parallel -------------------------------------------------------------------------
-    def set_data_parallel(self, process_group=None, bucket_mb: float = 25.0) -> None:
+    def set_data_parallel(self, process_group=None, bucket_mb: float = 8.0) -> None:
         from .dp import BucketReducer
         self.reducer = BucketReducer(self.layout.total, process_group, int(bucket_mb * (1 << 20)))
 
@@ -374,6 +374,8 @@ class TrainEngine:
             else:
                 ops.conv2d_dgrad(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=s, pad=1, residual=dzm)
             dz = dxin
+            # layout order inside a block is the reverse of module order: conv1.weight closes the block
+            self._maybe_reduce(flat, pref + "conv1.weight")
         # max-pool and the 7x7 stem conv (its input is the image: no dgrad)
         dc1 = self._scratch(b, ("dc1",), b["c1_z"])
         ops.maxpool3x3s2_bwd(dz, b["pool_arg"], dc1)
