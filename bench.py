@@ -24,6 +24,13 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 R_CFG = dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18")
+# BASELINE.json configs[3]: ViT-B/16-scale radar ViT (pure-ViT `patch16` layout), large-batch bf16 training
+VITB_CFG = dict(num_classes=11, embed_dim=768, num_heads=12, num_layers=12, dropout=0.1, backbone="patch16")
+VITB_FWD_FLOPS_PER_SAMPLE = 35.13e9
+# BASELINE.json configs[4]: ViT-L/16-scale inference, MX-fp8 weights + activations for the encoder GEMMs
+VITL_CFG = dict(num_classes=11, embed_dim=1024, num_heads=16, num_layers=24, dropout=0.1, backbone="patch16")
+VITL_FWD_FLOPS_PER_SAMPLE = 123.11e9
+FP8_MFMA_PEAK_TFLOPS = 5000.0        # dense, block-scaled f8f6f4 MFMA, MI355X_MICROARCH.md:444
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md:43
 HBM_PEAK_GBS = 8000.0            # spec, MI355X_MICROARCH.md:36
 FWD_FLOPS_PER_SAMPLE = 3.965e9   # BASELINE.md §2 (R hybrid)
@@ -58,7 +65,7 @@ def _say(rank, msg):
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
 
-def train_leg(args, dev, dist, world, rank, sd):
+def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PER_SAMPLE):
     """Secondary figure (BASELINE.json configs[3] shape on the R model): one optimiser step =
     forward in train() mode (BatchNorm batch statistics) + label-smoothed CE + backward on librvit +
     bucketed gradient all-reduce (N>1, overlapped with backward) + grad-norm clipping + AdamW
@@ -67,8 +74,11 @@ def train_leg(args, dev, dist, world, rank, sd):
     from vit_amd.loss import CrossEntropyLoss
     from vit_amd.model import CNNViTHybrid
     from vit_amd.synth import micro_doppler_batch
-    cfg = dict(R_CFG, dropout=args.train_dropout)
+    cfg = dict(R_CFG if cfg is None else cfg, dropout=args.train_dropout)
     model = CNNViTHybrid(**cfg)
+    if sd is None:
+        from vit_amd.synth import synth_state_dict
+        sd = synth_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed=0)
     model.load_state_dict(sd)
     model = model.to(dev).train()
     if world > 1:
@@ -126,8 +136,86 @@ def train_leg(args, dev, dist, world, rank, sd):
             "global_batch": world * B, "dropout": cfg["dropout"], "final_loss": round(float(loss), 4),
             "includes": "forward(train-mode BN) + CE(label_smoothing=0.05) + backward + "
                         + ("bucketed RCCL all-reduce + " if world > 1 else "") + "clip_grad_norm + fused AdamW",
-            "model_tflops": round(sps * 3 * FWD_FLOPS_PER_SAMPLE / 1e12, 2),
+            "model_tflops": round(sps * 3 * fwd_flops / 1e12, 2),
+            "mfma_util_model": round(sps * 3 * fwd_flops / 1e12 / (BF16_MFMA_PEAK_TFLOPS * world), 4),
             "kernel_ms_per_step": {n: round(v, 4) for n, v in sorted(kernels.items())}}
+
+
+def vitl_infer(args, dev, dist, world, rank):
+    """BASELINE.json configs[4]: ViT-L/16-scale forward, encoder Linears on the MX-fp8 MFMA; the same model in
+    bf16 is timed beside it.  Weights: random normal (std 0.02, torch generator) - throughput only."""
+    from vit_amd import ops
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.synth import micro_doppler_batch
+    torch.manual_seed(0)
+    model = CNNViTHybrid(**VITL_CFG)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.normal_(0.0, 0.02)
+    model = model.to(dev).eval()
+    B = args.batch if args.batch != 512 else 256   # configs[4] sweeps 8..1024; 256 unless --batch says otherwise
+    x = torch.cat([micro_doppler_batch(min(64, B - i), seed=1234 + 1000 * rank + i) for i in range(0, B, 64)]).to(dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    res = {}
+    kernels = {}
+    for prec in ("bf16", "mxfp8"):
+        model.set_inference_precision(prec)
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                model(x)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model(x)
+            sync()
+            dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res[prec] = dt
+        if rank == 0 and prec == "mxfp8":
+            rec = []
+            ops.set_profiler(rec)
+            with torch.no_grad():
+                for _ in range(2):
+                    model(x)
+            torch.cuda.synchronize(dev)
+            ops.set_profiler(None)
+            for name, e0, e1, fl, nb in rec:
+                k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+                k["launches"] += 1
+                k["ms"] += e0.elapsed_time(e1)
+                k["flops"] += fl
+    if rank != 0:
+        return
+    dt = res["mxfp8"]
+    value = world * B * args.steps / dt
+    g = kernels["gemm_mxfp8"]
+    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    out = {"metric": "inference_frames_per_sec", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-e4m3 (MX)",
+           "data": "synthetic",
+           "config": {"workload": "ViT-L/16-scale radar ViT (patch16, E1024/H16/L24, 11 classes) batched inference, "
+                                  "MX-fp8 encoder Linears (weights + activations), bf16 attention / LayerNorm",
+                      "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}"},
+           "model_tflops": round(value * VITL_FWD_FLOPS_PER_SAMPLE / 1e12, 2),
+           "mfma_util_model": round(value * VITL_FWD_FLOPS_PER_SAMPLE / 1e12 / (FP8_MFMA_PEAK_TFLOPS * world), 4),
+           "roofline": {"kernel": "gemm_mxfp8", "bound": "mfma", "achieved": round(ach, 2), "peak": FP8_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / FP8_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2)},
+           "bf16_same_model": {"value": round(world * B * args.steps / res["bf16"], 1), "unit": "frames/s",
+                               "ms_per_step": round(res["bf16"] / args.steps * 1e3, 3)},
+           "kernel_ms_per_step": {n: round(v["ms"] / 2, 4) for n, v in sorted(kernels.items())}}
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -141,6 +229,10 @@ def main():
     ap.add_argument("--train-steps", type=int, default=8)
     ap.add_argument("--train-dropout", type=float, default=0.1)
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput leg")
+    ap.add_argument("--workload", choices=["hybrid", "vitb-train", "vitl-infer-fp8"], default="hybrid",
+                    help="hybrid = the headline (BASELINE configs[1] inference + configs[2] training leg); "
+                         "vitb-train = BASELINE configs[3], ViT-B/16-scale training samples/s; "
+                         "vitl-infer-fp8 = BASELINE configs[4], ViT-L/16-scale MX-fp8 inference frames/s")
     args = ap.parse_args()
 
     if os.environ.get("RVIT_BENCH_VERBOSE"):  # where is every thread after 45 s?  (hang diagnosis)
@@ -164,6 +256,30 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+
+    if args.workload == "vitb-train":
+        tr = train_leg(args, dev, dist, world, rank, None, cfg=VITB_CFG, fwd_flops=VITB_FWD_FLOPS_PER_SAMPLE)
+        if rank == 0:
+            out = {"metric": "train_samples_per_sec", "value": tr["value"], "unit": "samples/s", "n_gpus": world,
+                   "steps": tr["steps"], "warmup": 3, "ms_per_step": tr["ms_per_step"], "higher_is_better": True,
+                   "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                   "config": {"workload": "ViT-B/16-scale radar ViT (patch16, E768/H12/L12, 11 classes) training step: "
+                                          + tr["includes"], "batch_per_gpu": tr["batch_per_gpu"],
+                              "global_batch": tr["global_batch"], "parallelism": f"dp{world}"},
+                   "model_tflops": tr["model_tflops"], "mfma_util_model": tr["mfma_util_model"],
+                   "kernel_ms_per_step": tr["kernel_ms_per_step"]}
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    if args.workload == "vitl-infer-fp8":
+        vitl_infer(args, dev, dist, world, rank)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from vit_amd import ops
     from vit_amd.model import CNNViTHybrid

@@ -76,6 +76,26 @@ int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra,
                    int r_period, int act, void* preact, int64_t ldp, int row_group, int row_extra, int drop_mode,
                    float drop_p, uint64_t drop_seed, int tile, void* stream);
 
+/* MX-fp8 GEMM on the block-scaled matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4):
+ *   C[M,N] = act( A_q[M,K] . B_q[N,K]^T + bias[n] ) + R
+ * A_q / B_q: OCP e4m3 bytes; SA / SB: E8M0 scale bytes, one per 32 consecutive K elements (OCP Microscaling
+ * MXFP8: element value = e4m3 * 2^(scale - 127)), stored TILED in the order the instruction consumes them:
+ * scale of (row r, block k/32) at byte ((r/16) * (K/128) + k/128) * 64 + (r%16) * 4 + (k/32)%4, rows padded
+ * to a multiple of 16.  fp32 accumulate.
+ * BASELINE.json configs[4] (ViT-L/16-scale fp8 inference): the encoder Linears, torch
+ * functional.py:5819-5833,6632-6637 and transformer.py:980-982.  No counterpart in the reference (fp32/fp16 only).
+ *   K % 128 == 0, N % 8 == 0; C (optional) bf16 / f32; R optional residual bf16 / f32; act RVIT_ACT_*;
+ *   Cq / SCq (optional, N % 128 == 0): MX-fp8 copy of the result (values + tiled scales) for the next GEMM. */
+int rvit_gemm_mxfp8(const void* A, int64_t lda, const void* SA, const void* B, int64_t ldb, const void* SB, void* C,
+                    int64_t ldc, int c_dtype, int64_t M, int N, int K, const float* bias, const void* R, int64_t ldr,
+                    int r_dtype, int act, void* Cq, int64_t ldcq, void* SCq, void* stream);
+
+/* MXFP8 quantisation: x (bf16 / f32) [rows, K] -> e4m3 q [rows, K] + E8M0 scales (tiled as above,
+ * ceil(rows/16)*16 * K/32 bytes); K % 128 == 0; scale = 2^(floor(log2 max|x_block|) - 8), values rounded to
+ * nearest even and saturated to +-448. */
+int rvit_quantize_mxfp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t rows, int K,
+                        void* stream);
+
 /* NHWC implicit-GEMM convolution, bf16 MFMA: y = act( scale[c]*conv(x, w) + bias[c] + residual ).
  * Replaces the timm resnet18 feature extractor convs + (eval-mode, folded) BatchNorm + ReLU +
  * BasicBlock residual add: `self.cnn_backbone(x)[-1]` (train_vit.py:87,145-146).

@@ -108,3 +108,33 @@ def test_mask_replay_restatement_equals_module_forward():
             assert torch.allclose(forward_with_masks(ref, x, ones, 0.0), ref(x), rtol=1e-4, atol=1e-5)
             assert torch.allclose(forward_with_masks(ref, x, ones, 0.0, features_only=True), ref.forward_features(x),
                                   rtol=1e-4, atol=1e-5)
+
+
+def test_mxfp8_emulation_restatement_and_format():
+    """oracle/ref_mxfp8.py: without quantisation it reproduces the module forward; the MXFP8 round trip obeys
+    the format (exact on powers of two and on e4m3-representable blocks, error bounded by the block maximum)."""
+    from oracle.ref_mxfp8 import forward_mxfp8_emulated, mx_dequantize, mx_fake_quant, mx_quantize
+    from oracle.ref_model import CNNViTHybridRef
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    cfg = dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=2, dropout=0.0, backbone="patch16")
+    ref = CNNViTHybridRef(**cfg)
+    ref.load_state_dict(synth_state_dict({k: v.shape for k, v in ref.state_dict().items()}, 3))
+    ref.eval()
+    x = micro_doppler_batch(2, seed=8)
+    with torch.no_grad():
+        assert torch.allclose(forward_mxfp8_emulated(ref, x, quantize=False), ref(x), rtol=1e-4, atol=1e-5)
+        d = (forward_mxfp8_emulated(ref, x) - ref(x)).abs().max().item()
+    assert 0.0 < d < 1.0                                   # quantisation changes the logits, moderately
+    # format checks
+    blk = torch.tensor([[1.0, -2.0, 0.5, 448.0] + [0.0] * 28])          # representable with scale 2^0
+    q, s = mx_quantize(blk)
+    assert int(s[0, 0]) == 127 and torch.equal(mx_dequantize(q, s), blk)
+    big = blk * 2.0 ** 20
+    q, s = mx_quantize(big)
+    assert int(s[0, 0]) == 147 and torch.equal(mx_dequantize(q, s), big)
+    z = torch.zeros(1, 32)
+    q, s = mx_quantize(z)
+    assert int(s[0, 0]) == 0 and torch.equal(mx_dequantize(q, s), z)
+    r = torch.randn(64, 256) * torch.exp(torch.randn(64, 1) * 4)
+    err = (mx_fake_quant(r) - r).reshape(64, 8, 32).abs().amax(2)
+    assert (err <= r.reshape(64, 8, 32).abs().amax(2) * 2.0 ** -3).all()

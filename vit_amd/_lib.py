@@ -35,6 +35,8 @@ SIGNATURES = {
     "rvit_last_error": ([], c_char_p),
     "rvit_gemm_bf16": ([P, L, I, I, P, L, P, L, I, L, I, I, P, P, P, L, I, P, L, I, I, I, P, L, I, I, I, F, U64, I, P],
                        c_int),
+    "rvit_gemm_mxfp8": ([P, L, P, P, L, P, P, L, I, L, I, I, P, P, L, I, I, P, L, P, P], c_int),
+    "rvit_quantize_mxfp8": ([P, I, L, P, L, P, L, I, P], c_int),
     "rvit_conv2d_fwd_bf16": ([P, P, P] + [I] * 12 + [P, P, P, I, I, P], c_int),
     "rvit_conv2d_dgrad_bf16": ([P, P, P] + [I] * 11 + [P, I, P], c_int),
     "rvit_conv2d_tokens_fwd": ([P, P, P] + [I] * 12 + [P, P, F, U64, I, P], c_int),

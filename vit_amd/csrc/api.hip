@@ -69,6 +69,27 @@ int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra,
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_gemm_mxfp8(const void* A, int64_t lda, const void* SA, const void* B, int64_t ldb, const void* SB, void* C,
+                    int64_t ldc, int c_dtype, int64_t M, int N, int K, const float* bias, const void* R, int64_t ldr,
+                    int r_dtype, int act, void* Cq, int64_t ldcq, void* SCq, void* stream) {
+  MxGemmArgs a{};
+  a.A = (const uint8_t*)A; a.lda = lda; a.SA = (const uint8_t*)SA;
+  a.B = (const uint8_t*)B; a.ldb = ldb; a.SB = (const uint8_t*)SB;
+  a.M = M; a.N = N; a.K = K;
+  a.C = C; a.ldc = ldc; a.c_f32 = c_dtype == RVIT_F32;
+  a.bias = bias; a.R = R; a.ldr = ldr; a.r_f32 = r_dtype == RVIT_F32; a.act = act;
+  a.Cq = (uint8_t*)Cq; a.ldcq = ldcq; a.SCq = (uint8_t*)SCq;
+  RVIT_CHECK_ARG(!C || c_dtype == RVIT_BF16 || c_dtype == RVIT_F32, "gemm_mxfp8: bad c_dtype %d", c_dtype);
+  return rvit_gemm_mxfp8_dispatch(a, (hipStream_t)stream);
+}
+
+int rvit_quantize_mxfp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t rows, int K,
+                        void* stream) {
+  RVIT_CHECK_ARG(x_dtype == RVIT_BF16 || x_dtype == RVIT_F32, "quantize_mxfp8: bad dtype %d", x_dtype);
+  return rvit_quantize_mx_impl(x, x_dtype == RVIT_F32, ldx, (uint8_t*)q, ldq, (uint8_t*)scales, rows, K,
+                               (hipStream_t)stream);
+}
+
 int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cpix, int seg_len, int KH,
                          int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* scale,
                          const float* bias, const void* residual, int act, int tile, void* stream) {

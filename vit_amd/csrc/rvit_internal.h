@@ -47,6 +47,32 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t stream);
 int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
                               int B, int relu, hipStream_t st);  // conv1.hip
 
+// Argument block of the MX-fp8 GEMM (gemm_mx.hip): C = act(A_q . B_q^T + bias) + R, optional MX copy of C.
+struct MxGemmArgs {
+  const uint8_t* A;   // e4m3 [M, lda]
+  long lda;
+  const uint8_t* SA;  // E8M0 scales, tiled [ceil(M/16)][K/128][16][4] (gemm_mx.hip)
+  const uint8_t* B;   // e4m3 [N, ldb]
+  long ldb;
+  const uint8_t* SB;  // E8M0 scales, tiled [ceil(N/16)][K/128][16][4]
+  long M;
+  int N, K;
+  void* C;            // bf16 / f32 [M, ldc], may be null when only the MX copy is wanted
+  long ldc;
+  int c_f32;
+  const float* bias;
+  const void* R;      // residual, added after the activation-free result (bf16 / f32), may be null
+  long ldr;
+  int r_f32;
+  int act;
+  uint8_t* Cq;        // optional e4m3 copy of the result [M, ldcq] ...
+  long ldcq;
+  uint8_t* SCq;       // ... with its E8M0 scales, tiled [ceil(M/16)][N/128][16][4]
+};
+int rvit_gemm_mxfp8_dispatch(const MxGemmArgs& a, hipStream_t st);
+int rvit_quantize_mx_impl(const void* x, int x_f32, long ldx, uint8_t* q, long ldq, uint8_t* sc, long rows, int K,
+                          hipStream_t st);
+
 // Argument block of the weight-gradient kernel (wgrad.hip): dW[N,K] += dY^T X.
 struct WgradArgs {
   const bf16* dY;  // [M, ldy]

@@ -50,11 +50,25 @@ class Engine:
         self._pack = None
         self._pack_key = None
         self._bufs: Dict[int, Dict[str, torch.Tensor]] = {}
+        # "bf16" or "mxfp8": the four encoder Linears of every layer on the block-scaled fp8 MFMA with MX
+        # (e4m3 + E8M0 per 32) weights and activations; LayerNorm, softmax, the residual stream, the stem, the
+        # patch embedding and the head stay bf16 / fp32 (BASELINE.json configs[4])
+        self.precision = "bf16"
+
+    def set_precision(self, precision: str) -> None:
+        if precision not in ("bf16", "mxfp8"):
+            raise ValueError(f"unknown inference precision {precision!r}; choose 'bf16' or 'mxfp8'")
+        if precision == "mxfp8" and (self.m.embed_dim % 128 != 0):
+            raise ValueError("mxfp8 needs embed_dim to be a multiple of 128")
+        if precision != self.precision:
+            self.precision = precision
+            self._pack = None
+            self._bufs.clear()
 
     # ---- weight packing ----------------------------------------------------------------------
     def _key(self):
         ps = list(self.m.parameters()) + list(self.m.buffers())
-        return (tuple(p._version for p in ps), ps[0].data_ptr(), ps[0].device, self.m.training)
+        return (tuple(p._version for p in ps), ps[0].data_ptr(), ps[0].device, self.m.training, self.precision)
 
     @torch.no_grad()
     def pack(self) -> dict:
@@ -103,6 +117,12 @@ class Engine:
                 fc1_w=L.linear1.weight.detach().to(BF16).contiguous(), fc1_b=L.linear1.bias.detach().float().contiguous(),
                 fc2_w=L.linear2.weight.detach().to(BF16).contiguous(), fc2_b=L.linear2.bias.detach().float().contiguous(),
                 eps1=L.norm1.eps, eps2=L.norm2.eps))
+            if self.precision == "mxfp8":  # weights quantised once, here, from the fp32 parameters (not from
+                d = layers[-1]             # their bf16 copies: double rounding flips ~3 % of the e4m3 values)
+                for nm, w in (("qkv_w", L.self_attn.in_proj_weight), ("out_w", L.self_attn.out_proj.weight),
+                              ("fc1_w", L.linear1.weight), ("fc2_w", L.linear2.weight)):
+                    del d[nm]
+                    d[nm + "_q"], d[nm + "_s"] = ops.quantize_mx(w.detach().float().contiguous())
         P["layers"] = layers
         P["norm_w"] = m.norm.weight.detach().float().contiguous()
         P["norm_b"] = m.norm.bias.detach().float().contiguous()
@@ -138,7 +158,14 @@ class Engine:
         b["ln"] = torch.empty(T, E, **z)
         b["qkv"] = torch.empty(T, 3 * E, **z)
         b["att"] = torch.empty(T, E, **z)
-        b["hid"] = torch.empty(T, 4 * E, **z)
+        if self.precision != "mxfp8":
+            b["hid"] = torch.empty(T, 4 * E, **z)
+        if self.precision == "mxfp8":
+            u8 = dict(dtype=torch.uint8, device=dev)
+            b["a_q"] = torch.empty(T, E, **u8)                        # MX copy of the LN / attention output
+            b["a_s"] = torch.zeros(ops.mx_scale_shape(T, E), **u8)
+            b["hid_q"] = torch.empty(T, 4 * E, **u8)                  # MX GELU output, written by linear1's epilogue
+            b["hid_s"] = torch.zeros(ops.mx_scale_shape(T, 4 * E), **u8)
         b["cls_ln"] = torch.empty(B, E, **z)
         b["h0"] = torch.empty(B, E // 2, **z)
         self._bufs[B] = b
@@ -178,6 +205,21 @@ class Engine:
         m = self.m
         E, S, H = m.embed_dim, m.num_patches + 1, m.num_heads
         x2 = b["x"].view(B * S, E)
+        if self.precision == "mxfp8":
+            aq, as_ = b["a_q"], b["a_s"]
+            ops.layernorm(x2, L["ln1_w"], L["ln1_b"], b["ln"], L["eps1"])
+            ops.quantize_mx(b["ln"], aq, as_)
+            ops.gemm_mx(aq, as_, L["qkv_w_q"], L["qkv_w_s"], b["qkv"], bias=L["qkv_b"])
+            ops.attention(b["qkv"], b["att"], B, S, H)
+            ops.quantize_mx(b["att"], aq, as_)
+            ops.gemm_mx(aq, as_, L["out_w_q"], L["out_w_s"], x2, bias=L["out_b"], residual=x2)
+            ops.layernorm(x2, L["ln2_w"], L["ln2_b"], b["ln"], L["eps2"])
+            ops.quantize_mx(b["ln"], aq, as_)
+            # linear1's epilogue emits the GELU output directly as MX-fp8 (no bf16 copy, no quantisation pass)
+            ops.gemm_mx(aq, as_, L["fc1_w_q"], L["fc1_w_s"], None, bias=L["fc1_b"], act="gelu", out_q=b["hid_q"],
+                        out_s=b["hid_s"])
+            ops.gemm_mx(b["hid_q"], b["hid_s"], L["fc2_w_q"], L["fc2_w_s"], x2, bias=L["fc2_b"], residual=x2)
+            return
         ops.layernorm(x2, L["ln1_w"], L["ln1_b"], b["ln"], L["eps1"])
         ops.gemm(b["ln"], L["qkv_w"], b["qkv"], bias=L["qkv_b"])
         ops.attention(b["qkv"], b["att"], B, S, H)

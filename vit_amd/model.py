@@ -213,6 +213,10 @@ class CNNViTHybrid(nn.Module):
             object.__setattr__(self, "_train_engine", TrainEngine(self))
         return self._train_engine
 
+    def set_inference_precision(self, precision: str) -> None:
+        """'bf16' (default) or 'mxfp8': encoder Linears on the block-scaled fp8 MFMA (eval mode only)."""
+        self.engine.set_precision(precision)
+
     def set_data_parallel(self, process_group=None, bucket_mb: float = 8.0) -> None:
         """Average gradients over `process_group` (RCCL) in buckets overlapped with backward."""
         self.train_engine.set_data_parallel(process_group, bucket_mb)

@@ -158,6 +158,68 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
     return out
 
 
+def mx_scale_shape(rows: int, K: int):
+    """Shape of the tiled E8M0 scale tensor of a [rows, K] MX-fp8 matrix (include/rvit.h)."""
+    return ((rows + 15) // 16, K // 128, 16, 4)
+
+
+def quantize_mx(x: torch.Tensor, q: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None):
+    """MXFP8: x bf16/f32 [rows, K] -> (q uint8 [rows, K] of e4m3 bytes, scales uint8 [ceil(rows/16), K/128, 16, 4])."""
+    _need_cuda(x, q, scales)
+    rows, K, ldx = _rows2d(x, "quantize_mx x")
+    if K % 128 or x.dtype not in (BF16, torch.float32):
+        raise ValueError("quantize_mx: K must be a multiple of 128, x bf16 or f32")
+    if q is None:
+        q = torch.empty(rows, K, dtype=torch.uint8, device=x.device)
+    if scales is None:
+        scales = torch.zeros(mx_scale_shape(rows, K), dtype=torch.uint8, device=x.device)
+    if q.shape != (rows, K) or tuple(scales.shape) != mx_scale_shape(rows, K) or q.dtype != torch.uint8 \
+            or scales.dtype != torch.uint8 or not scales.is_contiguous():
+        raise ValueError("quantize_mx: q [rows,K] / scales [ceil(rows/16),K/128,16,4] must be uint8")
+    with _Span("quantize_mx", 0, rows * K * (x.element_size() + 1)):
+        check(_lib.load().rvit_quantize_mxfp8(x.data_ptr(), _dt(x), ldx, q.data_ptr(), q.stride(0), scales.data_ptr(),
+                                              rows, K, _stream()), "rvit_quantize_mxfp8")
+    return q, scales
+
+
+def gemm_mx(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.Tensor, out: Optional[torch.Tensor], *,
+            bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: Optional[str] = None,
+            out_q: Optional[torch.Tensor] = None, out_s: Optional[torch.Tensor] = None):
+    """out = act(dequant(a) @ dequant(w).T + bias) + residual on the MX-fp8 MFMA; optional MX copy (out_q, out_s)."""
+    _need_cuda(a_q, a_s, w_q, w_s, out, bias, residual, out_q, out_s)
+    M, K, lda = _rows2d(a_q, "gemm_mx a")
+    N, K2, ldb = _rows2d(w_q, "gemm_mx w")
+    if K != K2 or K % 128 or any(t.dtype != torch.uint8 for t in (a_q, a_s, w_q, w_s)) \
+            or tuple(a_s.shape) != mx_scale_shape(M, K) or tuple(w_s.shape) != mx_scale_shape(N, K) \
+            or not (a_s.is_contiguous() and w_s.is_contiguous()):
+        raise ValueError("gemm_mx: operands must be uint8 [rows,K] (K % 128 == 0) with tiled uint8 scales")
+    if out is None and out_q is None:
+        raise ValueError("gemm_mx: no output")
+    ldc, c_dt = 0, RVIT_BF16
+    if out is not None:
+        mo, no, ldc = _rows2d(out, "gemm_mx out")
+        if (mo, no) != (M, N):
+            raise ValueError("gemm_mx: out shape mismatch")
+        c_dt = _dt(out)
+    ldr, r_dt = 0, RVIT_F32
+    if residual is not None:
+        rr, rn, ldr = _rows2d(residual, "gemm_mx residual")
+        if (rr, rn) != (M, N):
+            raise ValueError("gemm_mx: residual shape mismatch")
+        r_dt = _dt(residual)
+    if (out_q is None) != (out_s is None) or (out_q is not None and (
+            N % 128 or out_q.shape != (M, N) or tuple(out_s.shape) != mx_scale_shape(M, N)
+            or out_q.dtype != torch.uint8 or out_s.dtype != torch.uint8 or not out_s.is_contiguous())):
+        raise ValueError("gemm_mx: out_q [M,N] / tiled out_s must be uint8, N % 128 == 0, and come together")
+    _vec_f32(bias, N, "gemm_mx: bias")
+    with _Span("gemm_mxfp8", 2 * M * N * K, M * K + N * K + M * N * (out.element_size() if out is not None else 1)):
+        check(_lib.load().rvit_gemm_mxfp8(a_q.data_ptr(), lda, a_s.data_ptr(), w_q.data_ptr(), ldb, w_s.data_ptr(),
+                                          _ptr(out), ldc, c_dt, M, N, K, _ptr(bias), _ptr(residual), ldr, r_dt,
+                                          _ACT[act], _ptr(out_q), out_q.stride(0) if out_q is not None else 0,
+                                          _ptr(out_s), _stream()), "rvit_gemm_mxfp8")
+    return out if out is not None else out_q
+
+
 def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
            seg_len: Optional[int] = None, scale: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
