@@ -80,8 +80,9 @@ int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra,
  *   C[M,N] = act( A_q[M,K] . B_q[N,K]^T + bias[n] ) + R
  * A_q / B_q: OCP e4m3 bytes; SA / SB: E8M0 scale bytes, one per 32 consecutive K elements (OCP Microscaling
  * MXFP8: element value = e4m3 * 2^(scale - 127)), stored TILED in the order the instruction consumes them:
- * scale of (row r, block k/32) at byte ((r/16) * (K/128) + k/128) * 64 + (r%16) * 4 + (k/32)%4, rows padded
- * to a multiple of 16.  fp32 accumulate.
+ * as [ceil(rows/16)][ceil(K/512)][16][4][4] bytes, the scale of (row r, element k) at byte
+ * (((r/16) * ceil(K/512) + k/512) * 64 + (r%16) * 4 + (k/32)%4) * 4 + (k/128)%4; the caller zero-fills the
+ * padding.  fp32 accumulate.
  * BASELINE.json configs[4] (ViT-L/16-scale fp8 inference): the encoder Linears, torch
  * functional.py:5819-5833,6632-6637 and transformer.py:980-982.  No counterpart in the reference (fp32/fp16 only).
  *   K % 128 == 0, N % 8 == 0; C (optional) bf16 / f32; R optional residual bf16 / f32; act RVIT_ACT_*;
@@ -91,7 +92,7 @@ int rvit_gemm_mxfp8(const void* A, int64_t lda, const void* SA, const void* B, i
                     int r_dtype, int act, void* Cq, int64_t ldcq, void* SCq, void* stream);
 
 /* MXFP8 quantisation: x (bf16 / f32) [rows, K] -> e4m3 q [rows, K] + E8M0 scales (tiled as above,
- * ceil(rows/16)*16 * K/32 bytes); K % 128 == 0; scale = 2^(floor(log2 max|x_block|) - 8), values rounded to
+ * ceil(rows/16) * ceil(K/512) * 256 bytes); K % 128 == 0; scale = 2^(floor(log2 max|x_block|) - 8), values rounded to
  * nearest even and saturated to +-448. */
 int rvit_quantize_mxfp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, void* scales, int64_t rows, int K,
                         void* stream);

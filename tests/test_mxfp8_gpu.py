@@ -19,13 +19,14 @@ def mx_quantize_ref(x: torch.Tensor):
 
 
 def untile(s: torch.Tensor, rows: int, K: int) -> torch.Tensor:
-    """tiled scales [ceil(rows/16), K/128, 16, 4] -> row-major [rows, K/32]"""
-    return s.cpu().permute(0, 2, 1, 3).reshape(-1, K // 32)[:rows]
+    """tiled scales [ceil(rows/16), ceil(K/512), 16 rows, 4 blocks, 4 K tiles] -> row-major [rows, K/32]"""
+    t = s.cpu().permute(0, 2, 1, 4, 3)          # [row block, row, K group, K tile, block]
+    return t.reshape(t.shape[0] * 16, -1)[:rows, : K // 32]
 
 
 def mx_dequant(q: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
     rows, K = q.shape
-    if s.dim() == 4:
+    if s.dim() == 5:
         s = untile(s, rows, K)
     v = q.cpu().view(torch.float8_e4m3fn).float().reshape(rows, K // 32, 32)
     sc = torch.pow(2.0, s.cpu().double() - 127.0).float().unsqueeze(2)
@@ -111,7 +112,7 @@ def test_gemm_mx_rejects_bad_shapes(dev):
     from vit_amd import ops
     from vit_amd._lib import RvitError
     aq = torch.zeros(8, 64, dtype=torch.uint8, device=dev)
-    s = torch.zeros(1, 1, 16, 4, dtype=torch.uint8, device=dev)
+    s = torch.zeros(1, 1, 16, 4, 4, dtype=torch.uint8, device=dev)
     with pytest.raises((RvitError, ValueError)):
         ops.gemm_mx(aq, s, aq, s, torch.empty(8, 8, device=dev))   # K = 64 is not a multiple of 128
 

@@ -14,10 +14,11 @@
 // lane (r = lane&15, g = lane>>4) holds k = 16g..16g+15 in VGPRs 0-3 and k = 64+16g..64+16g+15 in
 // VGPRs 4-7 of row r (two ds_read_b128: chunks g and 4+g of the 128-byte row); the E8M0 scale of MX
 // block b (k = 32b..32b+31) of row r is taken from byte 0 of the scale VGPR of lane (r, g = b).
-// Scale matrices are therefore stored TILED, [ceil(rows/16)][K/128][16 rows][4 blocks] bytes: the 64
-// scales one instruction needs are 64 contiguous bytes, one per lane in lane order, fetched straight
-// from global with one coalesced byte load per fragment, one K tile ahead.  (Row-major [rows, K/32]
-// scales cost 16 cache lines per fragment load and made the kernel 2.8x slower than this layout.)
+// Scale matrices are therefore stored TILED, [ceil(rows/16)][ceil(K/512)][16 rows][4 blocks][4 K tiles]
+// bytes: a lane's scales for four consecutive K tiles are one dword, the 64 lanes of a fragment read 256
+// contiguous bytes, fetched straight from global once per four K tiles and one group ahead.  (Row-major
+// [rows, K/32] scales cost 16 cache lines per fragment load and made the kernel 2.8x slower; one byte
+// load per fragment per K tile was still 1.35x slower than this.)
 // Epilogue as gemm.hip (LDS restaging, 16-byte global accesses): bias, exact-erf GELU, residual,
 // f32 / bf16 output, and optionally an MX-fp8 copy of the result (values + E8M0 scales) so the next
 // GEMM consumes it without a separate quantisation pass.
@@ -52,6 +53,11 @@ __device__ __forceinline__ uint32_t mx_pack4(float a, float b, float c, float d,
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
   return (uint32_t)w;
+}
+// byte offset of the scale of (row r, element k) in the tiled scale matrix of a [rows, K] operand
+__device__ __forceinline__ long mx_scale_offset(long r, int k, int K) {
+  const int kt = k >> 7, nk4 = ((K >> 7) + 3) >> 2;
+  return ((((r >> 4) * nk4 + (kt >> 2)) * 64 + (r & 15) * 4 + ((k >> 5) & 3)) << 2) + (kt & 3);
 }
 __device__ __forceinline__ float mx_inv_scale(int s) { return __uint_as_float((uint32_t)(254 - s) << 23); }  // 2^(127-s)
 
@@ -107,29 +113,29 @@ __global__ __launch_bounds__(64 * MX_WAVES, 4) void gemm_mxfp8_kernel(const MxGe
   // ---- fragment / scale geometry -----------------------------------------------------------------
   const int fr = lane & 15, fq = lane >> 4;
   const int sw = (fr >> 1) & 7;
-  const int nk = p.K >> 7;
-  // tiled scales: byte ((row>>4) * nk + kt) * 64 + lane  (lane = (row&15)*4 + block ... in (fr, fq) terms fr*4 + fq)
-  const uint8_t* sa_blk[2];  // 16-row blocks past the padded row count are clamped: their data rows are zero pages
+  const int nk = p.K >> 7, nk4 = (nk + 3) >> 2;
+  // tiled scales: dword ((row>>4) * nk4 + kt/4) * 64 + (row&15)*4 + block, byte kt%4
+  const uint32_t* sa_blk[2];  // 16-row blocks past the padded row count are clamped: their data rows are zero pages
   const long mblk_last = (p.M + 15) / 16 - 1, nblk_last = (p.N + 15) / 16 - 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     long mb = (bm0 + wave * MX_WM + i * 16) >> 4;
     if (mb > mblk_last) mb = mblk_last;
-    sa_blk[i] = p.SA + mb * nk * 64 + fr * 4 + fq;
+    sa_blk[i] = reinterpret_cast<const uint32_t*>(p.SA) + mb * nk4 * 64 + fr * 4 + fq;
   }
-  const uint8_t* sb_blk[4];
+  const uint32_t* sb_blk[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     long nb = (bn0 + j * 16) >> 4;
     if (nb > nblk_last) nb = nblk_last;
-    sb_blk[j] = p.SB + nb * nk * 64 + fr * 4 + fq;
+    sb_blk[j] = reinterpret_cast<const uint32_t*>(p.SB) + nb * nk4 * 64 + fr * 4 + fq;
   }
-  int sa_w[2], sb_w[4];               // this lane's E8M0 scales of the tile in flight
-#define LOAD_SCALES(kt_)                                                                      \
+  uint32_t sa_w[2], sb_w[4], sa_n[2], sb_n[4];  // this lane's E8M0 scales: current group of 4 K tiles, next group
+#define LOAD_SCALES(g_, sa_, sb_)                                                             \
   do {                                                                                        \
-    const int ko_ = (kt_) * 64;                                                               \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) sa_w[i] = sa_blk[i][ko_];                   \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) sb_w[j] = sb_blk[j][ko_];                   \
+    const int go_ = (g_) * 64;                                                                \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) sa_[i] = sa_blk[i][go_];                    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) sb_[j] = sb_blk[j][go_];                    \
   } while (0)
 
   f32x4 acc[2][4];
@@ -139,18 +145,25 @@ __global__ __launch_bounds__(64 * MX_WAVES, 4) void gemm_mxfp8_kernel(const MxGe
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   ISSUE_TILE(0);
-  LOAD_SCALES(0);
+  LOAD_SCALES(0, sa_n, sb_n);
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile kt and its scales landed (this wave's share)
     __builtin_amdgcn_s_barrier();
+    if ((kt & 3) == 0) {                         // a new group of 4 K tiles: its scale dwords landed with this wait
+#pragma unroll
+      for (int i = 0; i < 2; ++i) sa_w[i] = sa_n[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sb_w[j] = sb_n[j];
+    }
+    const int sh = (kt & 3) * 8;
     int sa_s[2], sb_s[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) sa_s[i] = sa_w[i];
+    for (int i = 0; i < 2; ++i) sa_s[i] = (int)((sa_w[i] >> sh) & 0xff);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sb_s[j] = sb_w[j];
+    for (int j = 0; j < 4; ++j) sb_s[j] = (int)((sb_w[j] >> sh) & 0xff);
     ISSUE_TILE(stage ^ 1);                       // past K: zero pages
-    if (kt + 1 < nk) LOAD_SCALES(kt + 1);
+    if ((kt & 3) == 0 && kt + 4 < nk) LOAD_SCALES((kt >> 2) + 1, sa_n, sb_n);
     const char* sA = smem + stage * MX_TILE_BYTES;
     const char* sB = sA + MX_BM * 128;
     i32x8 af[2], bfr[4];
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(64 * MX_WAVES, 4) void gemm_mxfp8_kernel(const MxGe
         q.y = mx_pack4(v[4], v[5], v[6], v[7], inv);
         *reinterpret_cast<uint2*>(p.Cq + m * p.ldcq + n) = q;
         if ((lane & 3) == 0)  // tiled scale layout of the consumer GEMM (its K = this N)
-          p.SCq[((m >> 4) * (long)(p.N >> 7) + (n >> 7)) * 64 + (m & 15) * 4 + ((n >> 5) & 3)] = (uint8_t)s;
+          p.SCq[mx_scale_offset(m, n, p.N)] = (uint8_t)s;
       }
     }
   }
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256) void quantize_mx_kernel(const T* __restrict__ 
     o.x = mx_pack4(v[0], v[1], v[2], v[3], inv);
     o.y = mx_pack4(v[4], v[5], v[6], v[7], inv);
     *reinterpret_cast<uint2*>(q + r * ldq + c) = o;
-    if ((threadIdx.x & 3) == 0) sc[((r >> 4) * (long)(K >> 7) + (c >> 7)) * 64 + (r & 15) * 4 + ((c >> 5) & 3)] = (uint8_t)s;
+    if ((threadIdx.x & 3) == 0) sc[mx_scale_offset(r, c, K)] = (uint8_t)s;
   }
 }
 

@@ -51,10 +51,10 @@ int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale
 struct MxGemmArgs {
   const uint8_t* A;   // e4m3 [M, lda]
   long lda;
-  const uint8_t* SA;  // E8M0 scales, tiled [ceil(M/16)][K/128][16][4] (gemm_mx.hip)
+  const uint8_t* SA;  // E8M0 scales, tiled [ceil(M/16)][ceil(K/512)][16][4][4] (gemm_mx.hip)
   const uint8_t* B;   // e4m3 [N, ldb]
   long ldb;
-  const uint8_t* SB;  // E8M0 scales, tiled [ceil(N/16)][K/128][16][4]
+  const uint8_t* SB;  // E8M0 scales, tiled [ceil(N/16)][ceil(K/512)][16][4][4]
   long M;
   int N, K;
   void* C;            // bf16 / f32 [M, ldc], may be null when only the MX copy is wanted
@@ -67,7 +67,7 @@ struct MxGemmArgs {
   int act;
   uint8_t* Cq;        // optional e4m3 copy of the result [M, ldcq] ...
   long ldcq;
-  uint8_t* SCq;       // ... with its E8M0 scales, tiled [ceil(M/16)][N/128][16][4]
+  uint8_t* SCq;       // ... with its E8M0 scales, tiled [ceil(M/16)][ceil(N/512)][16][4][4]
 };
 int rvit_gemm_mxfp8_dispatch(const MxGemmArgs& a, hipStream_t st);
 int rvit_quantize_mx_impl(const void* x, int x_f32, long ldx, uint8_t* q, long ldq, uint8_t* sc, long rows, int K,

@@ -160,11 +160,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
 
 def mx_scale_shape(rows: int, K: int):
     """Shape of the tiled E8M0 scale tensor of a [rows, K] MX-fp8 matrix (include/rvit.h)."""
-    return ((rows + 15) // 16, K // 128, 16, 4)
+    return ((rows + 15) // 16, (K + 511) // 512, 16, 4, 4)
 
 
 def quantize_mx(x: torch.Tensor, q: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None):
-    """MXFP8: x bf16/f32 [rows, K] -> (q uint8 [rows, K] of e4m3 bytes, scales uint8 [ceil(rows/16), K/128, 16, 4])."""
+    """MXFP8: x bf16/f32 [rows, K] -> (q uint8 [rows, K] of e4m3 bytes, scales uint8 [ceil(rows/16), ceil(K/512), 16, 4, 4])."""
     _need_cuda(x, q, scales)
     rows, K, ldx = _rows2d(x, "quantize_mx x")
     if K % 128 or x.dtype not in (BF16, torch.float32):
@@ -175,7 +175,7 @@ def quantize_mx(x: torch.Tensor, q: Optional[torch.Tensor] = None, scales: Optio
         scales = torch.zeros(mx_scale_shape(rows, K), dtype=torch.uint8, device=x.device)
     if q.shape != (rows, K) or tuple(scales.shape) != mx_scale_shape(rows, K) or q.dtype != torch.uint8 \
             or scales.dtype != torch.uint8 or not scales.is_contiguous():
-        raise ValueError("quantize_mx: q [rows,K] / scales [ceil(rows/16),K/128,16,4] must be uint8")
+        raise ValueError("quantize_mx: q [rows,K] / tiled scales (ops.mx_scale_shape) must be uint8")
     with _Span("quantize_mx", 0, rows * K * (x.element_size() + 1)):
         check(_lib.load().rvit_quantize_mxfp8(x.data_ptr(), _dt(x), ldx, q.data_ptr(), q.stride(0), scales.data_ptr(),
                                               rows, K, _stream()), "rvit_quantize_mxfp8")
