@@ -9,7 +9,7 @@ N>1 is launched by torch.distributed.run, one rank per GPU; rank 0 prints ONE JS
 
 A "step" is one forward pass of the hot path (image pack -> stem -> patch embed -> encoder ->
 head) over one batch already resident in HBM.  `roofline` is measured live with HIP events around
-every launch of the dominant kernel (the implicit-GEMM conv); `cpu_baseline` times the torch fp32
+every launch of the dominant kernel (the LDS-resident 3x3 conv, csrc/conv3x3.hip); `cpu_baseline` times the torch fp32
 oracle (the reference's own torch.nn arithmetic) on this box's host cores on a bounded sample.
 """
 import argparse
@@ -355,13 +355,14 @@ def main():
     if rank == 0 and roofline is not None:
         roofline["algorithmic_bytes_per_launch"] = round(kernels[roofline["kernel"]]["bytes"] / kernels[roofline["kernel"]]["launches"])
         # HBM traffic of the same kernel from the committed PMC passes (profiles/, same command and batch)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_pmc_r01.json")
         if os.path.exists(pmc):
             with open(pmc) as fh:
                 t = json.load(fh)
             if t.get("kernel") == roofline["kernel"] and t.get("batch_per_gpu") == B:
                 roofline["traffic"] = t["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+                roofline["traffic_source"] = ("bench_pmc_r01.json = profiles/r01_pmc_traffic.json (rocprofv3 --pmc "
+                                              "FETCH_SIZE x2 + WRITE_SIZE, per launch, same command)")
     if rank == 0:
         frames = world * B * args.steps
         value = frames / dt

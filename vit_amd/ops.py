@@ -242,7 +242,12 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
     lib = _lib.load()
     # algorithmic work: true taps only (the 7x7 stem conv's zero taps / 4th channel are padding)
     true_k = kh * kw * seg if seg_len is None else kh * (kw * seg - seg // 8 - (seg - seg // 8) // 4)
-    with _Span("conv2d_bf16", 2 * B * Ho * Wo * Cout * true_k, _nbytes(x, w, out, residual)):
+    # the 3x3 / stride 1 / pad 1 convs run the LDS-resident-patch kernel (csrc/conv3x3.hip), everything else
+    # the implicit-GEMM gather kernel (csrc/gemm.hip): profile them under separate names
+    direct = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and seg_len is None and Cpix % 64 == 0
+              and Cout % 64 == 0 and (tile == 0 or 10 <= tile <= 13))
+    with _Span("conv3x3_direct" if direct else "conv2d_gather", 2 * B * Ho * Wo * Cout * true_k,
+               _nbytes(x, w, out, residual)):
         check(lib.rvit_conv2d_fwd_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cpix, seg, kh, kw, stride,
                                        pad, Ho, Wo, Cout, _ptr(scale), _ptr(bias), _ptr(residual), _ACT[act], tile,
                                        _stream()), "rvit_conv2d_fwd_bf16")
