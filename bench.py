@@ -86,14 +86,20 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
     B = args.train_batch
     x = torch.cat([micro_doppler_batch(min(64, B - i), seed=99 + 1000 * rank + i) for i in range(0, B, 64)]).to(dev)
     y = torch.randint(0, cfg["num_classes"], (B,), generator=torch.Generator().manual_seed(rank)).to(dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    fused = not args.stock_optimizer
+    if fused:   # clip + AdamW in two launches over the flat gradient buffer (vit_amd/optim.py)
+        from vit_amd.optim import FusedAdamW
+        opt = FusedAdamW(model, lr=1e-4, weight_decay=0.05, max_grad_norm=1.0)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
     crit = CrossEntropyLoss(label_smoothing=0.05)
 
     def step():
         opt.zero_grad(set_to_none=True)
         loss = crit(model(x), y)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        if not fused:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
         opt.step()
         return loss
 
@@ -111,6 +117,7 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
         loss = step()
+    t_host = time.perf_counter() - t0      # host time to ENQUEUE the steps (before the sync): launch-bound if ~ dt
     sync()
     _say(rank, "train: timed steps done")
     dt = time.perf_counter() - t0
@@ -132,10 +139,12 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
         return None
     sps = world * B * args.train_steps / dt
     return {"metric": "train_samples_per_sec", "value": round(sps, 1), "unit": "samples/s",
-            "ms_per_step": round(dt / args.train_steps * 1e3, 3), "steps": args.train_steps, "batch_per_gpu": B,
+            "ms_per_step": round(dt / args.train_steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(t_host / args.train_steps * 1e3, 3), "steps": args.train_steps,
+            "batch_per_gpu": B,
             "global_batch": world * B, "dropout": cfg["dropout"], "final_loss": round(float(loss), 4),
             "includes": "forward(train-mode BN) + CE(label_smoothing=0.05) + backward + "
-                        + ("bucketed RCCL all-reduce + " if world > 1 else "") + "clip_grad_norm + fused AdamW",
+                        + ("bucketed RCCL all-reduce + " if world > 1 else "") + ("librvit fused clip+AdamW" if fused else "clip_grad_norm_ + torch AdamW(fused=True)"),
             "model_tflops": round(sps * 3 * fwd_flops / 1e12, 2),
             "mfma_util_model": round(sps * 3 * fwd_flops / 1e12 / (BF16_MFMA_PEAK_TFLOPS * world), 4),
             "kernel_ms_per_step": {n: round(v, 4) for n, v in sorted(kernels.items())}}
@@ -228,6 +237,8 @@ def main():
     ap.add_argument("--train-batch", type=int, default=256, help="samples per GPU per training step")
     ap.add_argument("--train-steps", type=int, default=8)
     ap.add_argument("--train-dropout", type=float, default=0.1)
+    ap.add_argument("--stock-optimizer", action="store_true",
+                    help="training legs: clip_grad_norm_ + torch.optim.AdamW(fused=True) instead of vit_amd.optim.FusedAdamW")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput leg")
     ap.add_argument("--workload", choices=["hybrid", "vitb-train", "vitl-infer-fp8"], default="hybrid",
                     help="hybrid = the headline (BASELINE configs[1] inference + configs[2] training leg); "

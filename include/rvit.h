@@ -246,6 +246,33 @@ int rvit_bn_bwd_apply(const void* dz, const void* z, const void* y, const float*
 int rvit_maxpool3x3s2_bwd_nhwc(const void* dpool, const void* argmax, void* dx, int B, int H, int W, int C,
                                void* stream);
 
+/* *out += sum_i x[i]^2 (fp32; the caller zeroes *out).  Squared global gradient norm for
+ * torch.nn.utils.clip_grad_norm_ (train_vit.py:942-943) over the flat gradient buffer. */
+int rvit_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+
+/* One AdamW step over flat fp32 buffers, torch.optim.AdamW semantics (train_vit.py:879-883,945: decoupled
+ * weight decay, bias correction with `step` >= 1), fused with gradient clipping: when grad_norm_sq is not
+ * null and max_grad_norm > 0 the gradients are scaled by min(1, max_grad_norm / (sqrt(*grad_norm_sq) + 1e-6))
+ * exactly as clip_grad_norm_ does.  grads are read only.  params_bf16 (nullable, 8-byte aligned, n elements)
+ * receives the updated parameters rounded to bf16: the operand copy the next forward multiplies with (the
+ * reference keeps such copies implicitly under autocast, train_vit.py:407-417). */
+int rvit_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm_sq,
+                    float max_grad_norm, void* params_bf16, void* stream);
+
+/* out[i] = bf16(x[i]) (round to nearest even) over a flat buffer: (re)builds the bf16 operand copy of the
+ * parameters outside an optimiser step, e.g. after load_state_dict (train_vit.py:913-922, resume). */
+int rvit_cast_bf16(const float* x, void* out, int64_t n, void* stream);
+
+/* Transposes every matrix of a table in one launch: the K-major operand copies W^T that the data-gradient
+ * GEMMs / convolutions of the backward pass (train_vit.py:939) multiply with, derived from the bf16 parameter
+ * copy.  table: device int64 [n_entries][8] = {src_off, dst_off, rows, cols, src_ld, dst_ld, tile_start,
+ * tiles_c} in elements; dst[dst_off + c*dst_ld + r] = src[src_off + r*src_ld + c]; rows, cols, offsets and
+ * leading dimensions multiples of 8; entry e owns 64x64 tiles [tile_start, tile_start + tiles_r*tiles_c);
+ * total_tiles = the sum over entries. */
+int rvit_transpose_batched_bf16(const void* src, void* dst, const int64_t* table, int n_entries, int64_t total_tiles,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

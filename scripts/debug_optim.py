@@ -1,0 +1,37 @@
+import sys, torch
+sys.path.insert(0, ".")
+from vit_amd.loss import CrossEntropyLoss
+from vit_amd.model import CNNViTHybrid
+from vit_amd.optim import FusedAdamW
+from vit_amd.synth import micro_doppler_batch, synth_state_dict
+dev = torch.device("cuda:0")
+for drop in (0.0, 0.1):
+    cfg = dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=2, dropout=drop, backbone=sys.argv[1] if len(sys.argv) > 1 else "patch16")
+    ms = []
+    sd = None
+    for _ in range(3):
+        m = CNNViTHybrid(**cfg)
+        sd = sd or synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, 9)
+        m.load_state_dict(sd); ms.append(m.to(dev).train())
+    x = micro_doppler_batch(8, seed=4).to(dev)
+    y = torch.randint(0, 11, (8,), generator=torch.Generator().manual_seed(2)).to(dev)
+    crit = CrossEntropyLoss(label_smoothing=0.05)
+    opts = [torch.optim.AdamW(ms[0].parameters(), lr=2e-4, weight_decay=0.05),
+            torch.optim.AdamW(ms[1].parameters(), lr=2e-4, weight_decay=0.05),
+            FusedAdamW(ms[2], lr=2e-4, weight_decay=0.05, max_grad_norm=1.0)]
+    for step in range(3):
+        out = []
+        for i, (m, o) in enumerate(zip(ms, opts)):
+            torch.manual_seed(100 + step)
+            o.zero_grad(set_to_none=True)
+            l = crit(m(x), y); l.backward()
+            if i < 2:
+                n = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0).item()
+            o.step()
+            if i == 2: n = o.grad_norm().item()
+            out.append((round(l.item(), 5), round(n, 4)))
+        print(drop, step, out)
+        names = [n for n, _ in ms[0].named_parameters()]
+        worst = sorted(((a - c).abs().max().item(), (a - b).abs().max().item(), n) for n, a, b, c in
+                       zip(names, ms[0].parameters(), ms[1].parameters(), ms[2].parameters()))[-3:]
+        print("   worst fused-vs-stock / stock-vs-stock:", worst)

@@ -1,0 +1,262 @@
+"""Fused clip + AdamW step (vit_amd/optim.py, csrc/optim.hip) against clip_grad_norm_ + torch.optim.AdamW
+(train_vit.py:879-883,942-946) on identical models, inputs and dropout seeds: the parameters after several
+steps must agree to fp32 round-off, and the learning-rate schedule / state_dict plumbing must work."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kernels_against_torch_adamw(dev):
+    from vit_amd import _lib
+    from vit_amd.ops import _stream, check
+    lib = _lib.load()
+    n = 100_003
+    g0 = torch.Generator().manual_seed(1)
+    p = torch.randn(n, generator=g0).to(dev)
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref_p], lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    nsq = torch.zeros(1, device=dev)
+    mirror = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    for step in range(1, 6):
+        g = (torch.randn(n, generator=g0) * (3.0 if step % 2 else 0.001)).to(dev)   # clipped and unclipped steps
+        ref_p.grad = g.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        nsq.zero_()
+        check(lib.rvit_sumsq_f32(g.data_ptr(), n, nsq.data_ptr(), _stream()), "sumsq")
+        check(lib.rvit_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 3e-3, 0.9, 0.95, 1e-8,
+                                  0.05, step, nsq.data_ptr(), 1.0, mirror.data_ptr() if step > 1 else None,
+                                  _stream()), "adamw")
+        if step > 1:
+            assert torch.equal(mirror, p.to(torch.bfloat16))      # bf16 copy written by the same kernel
+        assert abs(nsq.sqrt().item() - want_norm.item()) <= 1e-4 * want_norm.item()
+        assert torch.allclose(p, ref_p.data, rtol=2e-5, atol=2e-6), step
+    st = opt.state[ref_p]
+    assert torch.allclose(m, st["exp_avg"], rtol=1e-5, atol=1e-7) and torch.allclose(v, st["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("backbone", ["patch16", "resnet18"])
+def test_fused_optimizer_matches_stock_loop(dev, backbone):
+    from vit_amd.loss import CrossEntropyLoss
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.optim import FusedAdamW
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    cfg = dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=2, dropout=0.1, backbone=backbone)
+    sd = None
+    models = []
+    for _ in range(2):
+        m = CNNViTHybrid(**cfg)
+        sd = sd or synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, 9)
+        m.load_state_dict(sd)
+        models.append(m.to(dev).train())
+    ma, mb = models
+    x = micro_doppler_batch(8, seed=4).to(dev)
+    y = torch.randint(0, 11, (8,), generator=torch.Generator().manual_seed(2)).to(dev)
+    crit = CrossEntropyLoss(label_smoothing=0.05)
+    stock = torch.optim.AdamW(ma.parameters(), lr=2e-4, weight_decay=0.05)
+    fused = FusedAdamW(mb, lr=2e-4, weight_decay=0.05, max_grad_norm=1.0)
+    sched_a = torch.optim.lr_scheduler.LambdaLR(stock, lambda e: (e + 1) / 3 if e < 3 else 0.5)
+    sched_b = torch.optim.lr_scheduler.LambdaLR(fused, lambda e: (e + 1) / 3 if e < 3 else 0.5)
+    # parameters became views of one flat buffer; values unchanged
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(pa, pb), n
+    losses = []
+    for step in range(4):
+        torch.manual_seed(100 + step)          # same dropout masks on both sides
+        stock.zero_grad(set_to_none=True)
+        la = crit(ma(x), y)
+        la.backward()
+        na = torch.nn.utils.clip_grad_norm_(ma.parameters(), 1.0)
+        stock.step()
+        sched_a.step()
+        torch.manual_seed(100 + step)
+        fused.zero_grad(set_to_none=True)
+        lb = crit(mb(x), y)
+        lb.backward()
+        fused.step()
+        sched_b.step()
+        losses.append((la.item(), lb.item()))
+        # two runs of the STOCK loop differ by ~1e-3 relative here (atomics order in the weight gradients, then
+        # Adam's g/|g| on noise-only gradients such as the K bias): measured in scripts/debug_optim.py
+        # (and BN over 8 samples amplifies it for the resnet stem): this loop is a plumbing check -- schedule, zero_grad,
+        # re-packing, trajectories alike -- the tight parity check is test_fused_step_same_gradients_tight
+        assert abs(la.item() - lb.item()) <= 0.1 * max(1.0, abs(la.item())), (step, la.item(), lb.item())
+        if step == 0:   # identical parameters only before the first update
+            assert abs(fused.grad_norm().item() - na.item()) <= 2e-2 * na.item()
+        assert stock.param_groups[0]["lr"] == pytest.approx(fused.param_groups[0]["lr"])
+    worst = 0.0
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        d = (pa - pb).abs().max().item()
+        worst = max(worst, d / max(1e-3, pa.abs().max().item()))
+    print(f"\n[{backbone}] losses {losses}; worst relative parameter difference after 4 steps {worst:.2e}")
+    # both sides run the same bf16 kernels; atomics in the weight gradients make runs differ in the last bits,
+    # Adam's normalisation keeps the per-step update bounded by lr: the copies stay within a few lr of each other
+    assert worst <= 2e-2
+    assert losses[-1][0] < losses[0][0] and losses[-1][1] < losses[0][1]
+    # eval on the updated weights works (the engines re-packed) and the two models still agree
+    ma.eval(); mb.eval()
+    with torch.no_grad():
+        assert torch.isfinite(mb(x)).all()   # eval-mode agreement is checked in the tight test below
+    # optimiser state round trip keeps the flat views
+    sd_opt = copy.deepcopy(fused.state_dict())
+    fused.load_state_dict(sd_opt)
+    p0 = next(iter(mb.parameters()))
+    assert fused.state[p0]["exp_avg"].data_ptr() == fused._eng.grads_in_param_order(fused.exp_avg)[0].data_ptr()
+
+
+@pytest.mark.parametrize("backbone", ["patch16", "resnet18"])
+def test_fused_step_same_gradients_tight(dev, backbone):
+    """Feed the SAME gradients to both optimisers every step (removes run-to-run gradient noise): parameters
+    must then track each other to fp32 round-off through clipped steps, for every layout (permuted conv views)."""
+    from vit_amd.loss import CrossEntropyLoss
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.optim import FusedAdamW
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    cfg = dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=2, dropout=0.1, backbone=backbone)
+    ma, mb = CNNViTHybrid(**cfg), CNNViTHybrid(**cfg)
+    sd = synth_state_dict({k: v.shape for k, v in ma.state_dict().items()}, 5)
+    ma.load_state_dict(sd); mb.load_state_dict(sd)
+    ma, mb = ma.to(dev).train(), mb.to(dev).train()
+    stock = torch.optim.AdamW(ma.parameters(), lr=5e-4, weight_decay=0.05)
+    fused = FusedAdamW(mb, lr=5e-4, weight_decay=0.05, max_grad_norm=1.0)
+    x = micro_doppler_batch(8, seed=6).to(dev)
+    y = torch.randint(0, 11, (8,), generator=torch.Generator().manual_seed(3)).to(dev)
+    crit = CrossEntropyLoss(label_smoothing=0.05)
+    for step in range(3):
+        fused.zero_grad(set_to_none=True)
+        crit(mb(x), y).backward()
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            pa.grad = pb.grad.detach().clone()
+        want_norm = torch.nn.utils.clip_grad_norm_(ma.parameters(), 1.0)
+        stock.step()
+        fused.step()
+        assert abs(fused.grad_norm().item() - want_norm.item()) <= 1e-4 * want_norm.item()
+        for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-6), (step, n, (pa - pb).abs().max().item())
+    # the inference engine re-packed the updated weights: eval logits of the two copies agree (bf16 pack of
+    # parameters equal to ~1e-6; running BN statistics were only updated on mb, so copy them over first)
+    ma.load_state_dict(mb.state_dict())
+    ma.eval(); mb.eval()
+    with torch.no_grad():
+        assert torch.allclose(ma(x), mb(x), atol=1e-3)
+
+
+def _flatten(node, pref=""):
+    if torch.is_tensor(node):
+        yield pref, node
+    elif isinstance(node, dict):
+        for k, v in node.items():
+            yield from _flatten(v, f"{pref}.{k}")
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            yield from _flatten(v, f"{pref}[{i}]")
+
+
+@pytest.mark.parametrize("backbone", ["patch16", "resnet18"])
+def test_weight_mirror_equals_torch_packs(dev, backbone):
+    """The operand copies kept by the optimiser kernel (bf16 mirror views + one batched transpose) are bit-identical
+    to the per-tensor torch packs of the same parameters, before and after steps and after load_state_dict."""
+    from vit_amd.loss import CrossEntropyLoss
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.optim import FusedAdamW
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    from vit_amd.trainer import _TorchPacker
+    m = CNNViTHybrid(num_classes=11, embed_dim=128, num_heads=2, num_layers=2, dropout=0.0, backbone=backbone)
+    m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, 5))
+    m = m.to(dev).train()
+    opt = FusedAdamW(m, lr=1e-2, weight_decay=0.05, max_grad_norm=1.0)
+    eng = m.train_engine
+
+    def check(tag):
+        want = dict(_flatten(eng._build_pack(_TorchPacker(m))))
+        got = dict(_flatten(eng.pack()))
+        assert want.keys() == got.keys()
+        for k in want:
+            assert want[k].shape == got[k].shape and want[k].dtype == got[k].dtype, (tag, k)
+            assert torch.equal(want[k], got[k]), (tag, k)
+
+    check("initial")
+    x = micro_doppler_batch(4, seed=6).to(dev)
+    y = torch.tensor([1, 2, 3, 4], device=dev)
+    crit = CrossEntropyLoss()
+    before = m.head["3"].weight.detach().clone()
+    for step in range(2):
+        opt.zero_grad(set_to_none=True)
+        crit(m(x), y).backward()
+        opt.step()
+        check(f"after step {step}")
+    assert not torch.equal(before, m.head["3"].weight)
+    m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, 8))
+    check("after load_state_dict")          # version counters moved -> full refresh
+
+
+def test_batched_transpose_ragged_tiles(dev):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(200_000, generator=g).to(dev).to(torch.bfloat16)
+    shapes = [(8, 8), (72, 40), (64, 64), (136, 264), (24, 1000)]
+    entries, off_s, off_d, want = [], 0, 0, []
+    for r, c in shapes:
+        ld = c + 16                                  # a padded source pitch
+        entries.append((off_s, off_d, r, c, ld, r))
+        want.append((off_d, src[off_s:off_s + r * ld].view(r, ld)[:, :c].t().contiguous()))
+        off_s += (r * ld + 63) // 64 * 64
+        off_d += (r * c + 63) // 64 * 64
+    dst = torch.zeros(off_d, dtype=torch.bfloat16, device=dev)
+    ops.transpose_batched(src, dst, ops.transpose_table(entries, dev))
+    for (o, w), (r, c) in zip(want, shapes):
+        assert torch.equal(dst[o:o + r * c].view(c, r), w), (r, c)
+    with pytest.raises(ValueError):
+        ops.transpose_table([(0, 0, 12, 8, 8, 12)], dev)      # rows not a multiple of 8
+    with pytest.raises(ValueError):
+        ops.transpose_batched(src[:100], dst, ops.transpose_table(entries, dev))
+
+
+@pytest.mark.parametrize("fused_flag", [True, False])
+def test_stock_optimizers_never_see_stale_weights(dev, fused_flag):
+    """torch.optim.AdamW(fused=True) updates parameters WITHOUT bumping their version counters: the engines must
+    not rely on those to notice an optimiser step (regression: the training forward kept multiplying with the
+    packed copies of the initial weights)."""
+    from vit_amd.loss import CrossEntropyLoss
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    cfg = dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=1, dropout=0.0, backbone="patch16")
+    m = CNNViTHybrid(**cfg)
+    m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, 5))
+    m = m.to(dev)
+    x = micro_doppler_batch(4, seed=6).to(dev)
+    y = torch.tensor([1, 2, 3, 4], device=dev)
+    m.eval()
+    with torch.no_grad():
+        m(x)                                     # inference engine packs the initial weights
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=fused_flag)
+    crit = CrossEntropyLoss()
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        crit(m(x), y).backward()
+        opt.step()
+    # a fresh model with the trained weights is the yardstick for both engines
+    fresh = CNNViTHybrid(**cfg)
+    fresh.load_state_dict(m.state_dict())
+    fresh = fresh.to(dev)
+    with torch.no_grad():
+        m.train(); fresh.train()
+        assert torch.equal(m(x), fresh(x))       # training engine (dropout 0, patch16: deterministic forward)
+        m.eval(); fresh.eval()
+        assert torch.equal(m(x), fresh(x))       # inference engine
+
+
+def test_fused_optimizer_requires_engine_gradients(dev):
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.optim import FusedAdamW
+    m = CNNViTHybrid(num_classes=11, embed_dim=128, num_heads=2, num_layers=1, dropout=0.0, backbone="patch16").to(dev)
+    opt = FusedAdamW(m, lr=1e-3)
+    with pytest.raises(RuntimeError):
+        opt.step()
+    with pytest.raises(RuntimeError):
+        FusedAdamW(CNNViTHybrid(num_classes=11, embed_dim=128, num_heads=2, num_layers=1, backbone="patch16"))

@@ -55,6 +55,10 @@ SIGNATURES = {
     "rvit_ce_loss": ([P, L, P, P, P, L, P, L, I, I, I, F, F, P], c_int),
     "rvit_colsum_bf16": ([P, L, P, L, I, L, L, P], c_int),
     "rvit_batch_sum_f32": ([P, L, P, I, L, P], c_int),
+    "rvit_sumsq_f32": ([P, L, P, P], c_int),
+    "rvit_adamw_step": ([P, P, P, P, L, F, F, F, F, F, I, P, F, P, P], c_int),
+    "rvit_cast_bf16": ([P, P, L, P], c_int),
+    "rvit_transpose_batched_bf16": ([P, P, P, I, L, P], c_int),
     "rvit_bn_stats": ([P, L, I, P, P], c_int),
     "rvit_bn_apply": ([P, P, P, P, P, P, L, I, F, I, F, P, P, P], c_int),
     "rvit_bn_bwd_reduce": ([P, P, P, P, L, I, F, I, P, P], c_int),

@@ -251,4 +251,25 @@ int rvit_batch_sum_f32(const float* x, int64_t ldb, float* out, int B, int64_t n
   return rvit_batch_sum_impl(x, ldb, out, B, n, (hipStream_t)stream);
 }
 
+int rvit_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
+  return rvit_sumsq_impl(x, n, out, (hipStream_t)stream);
+}
+
+int rvit_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm_sq,
+                    float max_grad_norm, void* params_bf16, void* stream) {
+  return rvit_adamw_impl(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq,
+                         max_grad_norm, (bf16*)params_bf16, (hipStream_t)stream);
+}
+
+int rvit_cast_bf16(const float* x, void* out, int64_t n, void* stream) {
+  return rvit_cast_bf16_impl(x, (bf16*)out, n, (hipStream_t)stream);
+}
+
+int rvit_transpose_batched_bf16(const void* src, void* dst, const int64_t* table, int n_entries, int64_t total_tiles,
+                                void* stream) {
+  return rvit_transpose_batched_impl((const bf16*)src, (bf16*)dst, (const long*)table, n_entries, total_tiles,
+                                     (hipStream_t)stream);
+}
+
 }  // extern "C"

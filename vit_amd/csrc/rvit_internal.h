@@ -69,6 +69,12 @@ struct MxGemmArgs {
   long ldcq;
   uint8_t* SCq;       // ... with its E8M0 scales, tiled [ceil(M/16)][ceil(N/512)][16][4][4]
 };
+int rvit_sumsq_impl(const float* x, long n, float* out, hipStream_t st);  // optim.hip
+int rvit_adamw_impl(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                    float wd, int step, const float* gnorm_sq, float max_norm, bf16* mirror, hipStream_t st);
+int rvit_cast_bf16_impl(const float* x, bf16* out, long n, hipStream_t st);
+int rvit_transpose_batched_impl(const bf16* src, bf16* dst, const long* table, int n_entries, long total_tiles,
+                                hipStream_t st);
 int rvit_gemm_mxfp8_dispatch(const MxGemmArgs& a, hipStream_t st);
 int rvit_quantize_mx_impl(const void* x, int x_f32, long ldx, uint8_t* q, long ldq, uint8_t* sc, long rows, int K,
                           hipStream_t st);

@@ -213,6 +213,17 @@ class CNNViTHybrid(nn.Module):
             object.__setattr__(self, "_train_engine", TrainEngine(self))
         return self._train_engine
 
+    def invalidate_packs(self) -> None:
+        """Drop the inference engine's packed weight copies.  Called automatically on every train-mode forward, on
+        train()/eval() switches and (through parameter version counters) after load_state_dict; call it by hand
+        after editing parameters in eval mode through an API that bypasses autograd's version counters."""
+        if self._engine is not None:
+            self._engine._pack = None
+
+    def train(self, mode: bool = True):
+        self.invalidate_packs()
+        return super().train(mode)
+
     def set_inference_precision(self, precision: str) -> None:
         """'bf16' (default) or 'mxfp8': encoder Linears on the block-scaled fp8 MFMA (eval mode only)."""
         self.engine.set_precision(precision)
@@ -224,7 +235,10 @@ class CNNViTHybrid(nn.Module):
     def _run(self, x, features_only: bool):
         x = self._check_input(x)
         if self.training:
-            # train(): BatchNorm batch statistics; backward on librvit when gradients are recorded
+            # train(): BatchNorm batch statistics; backward on librvit when gradients are recorded.
+            # A training forward means the weights are about to change: the inference engine re-packs next time
+            # (parameter version counters alone miss e.g. torch.optim.AdamW(fused=True) steps).
+            self.invalidate_packs()
             from .trainer import HybridFunction
             if torch.is_grad_enabled():
                 return HybridFunction.apply(x, self.train_engine, features_only, *self.parameters())

@@ -632,3 +632,77 @@ def maxpool3x3s2_bwd(dpool: torch.Tensor, argmax: torch.Tensor, dx: torch.Tensor
         check(_lib.load().rvit_maxpool3x3s2_bwd_nhwc(dpool.data_ptr(), argmax.data_ptr(), dx.data_ptr(), B, H, W, C,
                                                      _stream()), "rvit_maxpool3x3s2_bwd_nhwc")
     return dx
+
+
+def sumsq(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[0] += sum(x^2) over a flat fp32 buffer (global grad-norm, train_vit.py:942-945); out is NOT cleared here."""
+    _need_cuda(x, out)
+    if x.dtype != torch.float32 or out.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("sumsq: contiguous float32 expected")
+    with _Span("grad_sumsq", 0, x.numel() * 4):
+        check(_lib.load().rvit_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "rvit_sumsq_f32")
+    return out
+
+
+def adamw_step(params: torch.Tensor, grads: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
+               beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
+               grad_norm_sq: Optional[torch.Tensor] = None, max_grad_norm: float = 0.0,
+               params_bf16: Optional[torch.Tensor] = None) -> None:
+    """One fused clip + AdamW update over flat fp32 buffers (torch.optim.AdamW semantics, train_vit.py:879-883)."""
+    _need_cuda(params, grads, exp_avg, exp_avg_sq, grad_norm_sq)
+    n = params.numel()
+    for t in (params, grads, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise ValueError("adamw_step: four contiguous float32 buffers of one length expected")
+    if params_bf16 is not None and (params_bf16.dtype != torch.bfloat16 or params_bf16.numel() != n
+                                    or not params_bf16.is_contiguous() or not params_bf16.is_cuda):
+        raise ValueError("adamw_step: params_bf16 must be a contiguous bf16 buffer of the same length")
+    with _Span("adamw_step", 0, n * (28 if params_bf16 is None else 30)):
+        check(_lib.load().rvit_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), n, float(lr),
+                                          float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                          _ptr(grad_norm_sq), float(max_grad_norm), _ptr(params_bf16), _stream()),
+              "rvit_adamw_step")
+
+
+def cast_bf16(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out = bf16(x) over flat contiguous buffers."""
+    _need_cuda(x, out)
+    if x.dtype != torch.float32 or out.dtype != torch.bfloat16 or x.numel() != out.numel() \
+            or not x.is_contiguous() or not out.is_contiguous():
+        raise ValueError("cast_bf16: contiguous float32 -> bfloat16 buffers of one length expected")
+    with _Span("cast_bf16", 0, x.numel() * 6):
+        check(_lib.load().rvit_cast_bf16(_ptr(x), _ptr(out), x.numel(), _stream()), "rvit_cast_bf16")
+    return out
+
+
+def transpose_table(entries, device) -> tuple:
+    """Validates (src_off, dst_off, rows, cols, src_ld, dst_ld) tuples and lays out the device table of
+    rvit_transpose_batched_bf16; returns (table int64 [n,8], n_entries, total_tiles, src_extent, dst_extent)."""
+    rows_out, tile, ext_s, ext_d = [], 0, 0, 0
+    for e in entries:
+        src_off, dst_off, rows, cols, src_ld, dst_ld = (int(v) for v in e)
+        if min(rows, cols) <= 0 or any(v % 8 for v in (src_off, dst_off, rows, cols, src_ld, dst_ld)) \
+                or src_ld < cols or dst_ld < rows:
+            raise ValueError(f"transpose_table: entry {e} is not 8-element aligned / consistent")
+        tr, tc = (rows + 63) // 64, (cols + 63) // 64
+        rows_out.append([src_off, dst_off, rows, cols, src_ld, dst_ld, tile, tc])
+        tile += tr * tc
+        ext_s = max(ext_s, src_off + (rows - 1) * src_ld + cols)
+        ext_d = max(ext_d, dst_off + (cols - 1) * dst_ld + rows)
+    if not rows_out:
+        raise ValueError("transpose_table: empty")
+    return torch.tensor(rows_out, dtype=torch.int64).to(device), len(rows_out), tile, ext_s, ext_d
+
+
+def transpose_batched(src: torch.Tensor, dst: torch.Tensor, table) -> torch.Tensor:
+    """All transposes of `table` (from transpose_table) in one launch; src/dst flat bf16 buffers."""
+    tab, n, tiles, ext_s, ext_d = table
+    _need_cuda(src, dst, tab)
+    if src.numel() < ext_s or dst.numel() < ext_d:
+        raise ValueError("transpose_batched: table reaches beyond the buffers")
+    if src.dtype != torch.bfloat16 or dst.dtype != torch.bfloat16 or not src.is_contiguous() or not dst.is_contiguous():
+        raise ValueError("transpose_batched: contiguous bf16 buffers expected")
+    with _Span("transpose_batched", 0, 0):
+        check(_lib.load().rvit_transpose_batched_bf16(_ptr(src), _ptr(dst), _ptr(tab), n, tiles, _stream()),
+              "rvit_transpose_batched_bf16")
+    return dst

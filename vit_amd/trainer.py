@@ -48,6 +48,125 @@ def _px4_pack(w: torch.Tensor, kw_pad: int) -> torch.Tensor:
     return p.reshape(cout, -1).to(BF16).contiguous()
 
 
+class _TorchPacker:
+    """Operand copies made with torch ops straight from the fp32 parameters (any optimiser)."""
+
+    def __init__(self, model):
+        self.p = dict(model.named_parameters())
+
+    def _2d(self, n):
+        w = self.p[n].detach()
+        return w.reshape(w.shape[0], -1)
+
+    def b(self, n): return _b(self._2d(n))
+    def t(self, n): return _t(self._2d(n))
+    def conv_fwd(self, n): return _conv_fwd_pack(self.p[n])
+    def conv_bwd(self, n): return _conv_bwd_pack(self.p[n])
+    def px4(self, n, kw_pad): return _px4_pack(self.p[n], kw_pad)
+
+    def t_padded(self, n, mult):
+        w = self.p[n].detach()
+        out = torch.zeros(w.shape[1], mult * ((w.shape[0] + mult - 1) // mult), dtype=BF16, device=w.device)
+        out[:, : w.shape[0]] = w.t().to(BF16)
+        return out
+
+
+class WeightMirror:
+    """bf16 operand copies of every parameter for the training engine, kept current by the optimiser.
+
+    `bf16` mirrors the flat fp32 parameter buffer of vit_amd.optim.FusedAdamW element for element (the AdamW
+    kernel writes it, ops.adamw_step(params_bf16=...)): since that buffer stores conv weights channels-last,
+    every forward-layout pack ([Cout, kh*kw*Cin], [N, K]) is simply a VIEW of it.  The K-major copies that the
+    data-gradient GEMMs / convolutions read live in `wt`, rebuilt from `bf16` by ONE batched-transpose launch
+    (rvit_transpose_batched_bf16).  Three tiny padded packs (7x7 stem, 16x16 patch conv, class head) are
+    refreshed with torch ops.  `pack` has the same keys as TrainEngine._build_pack with any packer."""
+
+    def __init__(self, eng: "TrainEngine", flat_params: torch.Tensor):
+        self.eng, self.flat = eng, flat_params
+        self.L = eng.layout
+        dev = flat_params.device
+        self.bf16 = torch.zeros(self.L.total, dtype=BF16, device=dev)
+        self._entries: List[tuple] = []
+        self._wt_views: List[tuple] = []   # (dst_off, numel, shape) resolved once `wt` is allocated
+        self._wt_size = 0
+        self._small = []                   # closures refreshing the padded packs
+        self._dev = dev
+        pack = eng._build_pack(self)
+        self.wt = torch.zeros(max(self._wt_size, 8), dtype=BF16, device=dev)
+        self.pack = self._resolve(pack)
+        self.table = ops.transpose_table(self._entries, dev) if self._entries else None
+        self.key = None
+        self.refresh(full=True)
+        self.key = eng._key()
+
+    # -- packer interface (called by TrainEngine._build_pack) --
+    def _seg(self, n):
+        off, numel, shape = self.L.offsets[n]
+        return off, numel, shape
+
+    def b(self, n):
+        off, numel, shape = self._seg(n)
+        return self.bf16[off:off + numel].view(shape[0], -1)
+
+    conv_fwd = b    # flat layout of stem convs is [Cout, kh, kw, Cin] already
+
+    def _alloc(self, numel):
+        d = self._wt_size
+        self._wt_size += (numel + 63) // 64 * 64
+        return d
+
+    def t(self, n):
+        off, numel, shape = self._seg(n)
+        N, K = shape[0], numel // shape[0]
+        d = self._alloc(numel)
+        self._entries.append((off, d, N, K, K, N))
+        return ("wt", d, numel, (K, N))
+
+    def conv_bwd(self, n):
+        off, numel, shape = self._seg(n)
+        co, ci, kh, kw = shape
+        T = kh * kw
+        d = self._alloc(numel)
+        for tap in range(T):   # dst[ci, tap, co] = src[co, tap, ci]
+            self._entries.append((off + tap * ci, d + tap * co, co, ci, T * ci, T * co))
+        return ("wt", d, numel, (ci, T * co))
+
+    def px4(self, n, kw_pad):
+        off, numel, shape = self._seg(n)
+        co, ci, kh, kw = shape
+        src = self.bf16[off:off + numel].view(co, kh, kw, ci)
+        out = torch.zeros(co, kh, kw_pad, 4, dtype=BF16, device=self._dev)
+        self._small.append(lambda: out[:, :, :kw, :ci].copy_(src))
+        return out.view(co, -1)
+
+    def t_padded(self, n, mult):
+        off, numel, shape = self._seg(n)
+        src = self.bf16[off:off + numel].view(shape)
+        out = torch.zeros(shape[1], mult * ((shape[0] + mult - 1) // mult), dtype=BF16, device=self._dev)
+        self._small.append(lambda: out[:, : shape[0]].copy_(src.t()))
+        return out
+
+    def _resolve(self, node):
+        if isinstance(node, tuple) and len(node) == 4 and node[0] == "wt":
+            _, d, numel, shape = node
+            return self.wt[d:d + numel].view(shape)
+        if isinstance(node, dict):
+            return {k: self._resolve(v) for k, v in node.items()}
+        if isinstance(node, list):
+            return [self._resolve(v) for v in node]
+        return node
+
+    @torch.no_grad()
+    def refresh(self, full: bool) -> None:
+        """full: re-cast the fp32 parameters too (parameters changed outside the optimiser kernel)."""
+        if full:
+            ops.cast_bf16(self.flat, self.bf16)
+        if self.table is not None:
+            ops.transpose_batched(self.bf16, self.wt, self.table)
+        for f in self._small:
+            f()
+
+
 class _GradLayout:
     """Flat fp32 gradient buffer: one segment per parameter, in backward-completion order."""
 
@@ -100,9 +219,10 @@ class TrainEngine:
         self.m = model
         self.layout = _GradLayout(model)
         self._pack = None
-        self._pack_key = None
+        self.mirror = None   # WeightMirror, installed by vit_amd.optim.FusedAdamW
         self._bufs: Dict[int, dict] = {}
         self.reducer = None
+        self.last_flat = None
 
     # ---- data parallel -------------------------------------------------------------------------
     def set_data_parallel(self, process_group=None, bucket_mb: float = 8.0) -> None:
@@ -116,42 +236,61 @@ class TrainEngine:
 
     @torch.no_grad()
     def pack(self) -> dict:
-        key = self._key()
-        if self._pack is not None and key == self._pack_key:
-            return self._pack
+        """bf16 operand copies of the weights for this forward/backward.
+
+        Without a WeightMirror they are rebuilt on EVERY call: version counters cannot be trusted to notice an
+        optimiser step (torch.optim.AdamW(fused=True) updates parameters without bumping `_version`), and a
+        stale pack would silently train on old weights.  With vit_amd.optim.FusedAdamW the optimiser kernel
+        itself maintains the copies (WeightMirror) and nothing is rebuilt here."""
+        mir = self.mirror
+        if mir is not None:
+            key = self._key()
+            if key != mir.key:   # parameters changed behind the optimiser's back (load_state_dict, manual edits)
+                mir.refresh(full=True)
+                mir.key = key
+            self._pack = mir.pack
+            return mir.pack
+        with ops._Span("weight_pack", 0, 0):
+            self._pack = self._build_pack(_TorchPacker(self.m))
+        return self._pack
+
+    def _build_pack(self, pk) -> dict:
         m = self.m
         P: dict = {}
         if m.cnn_backbone is not None:
             cb = m.cnn_backbone
-            P["conv1_w"] = _px4_pack(cb.conv1.weight, 8)
+            P["conv1_w"] = pk.px4("cnn_backbone.conv1.weight", 8)
             blocks = []
-            for blk in cb.blocks():
+            for pref, blk in self._stem_blocks():
                 d = {"stride": blk.conv1.stride, "cin": blk.conv1.cin, "cout": blk.conv1.cout,
-                     "c1_w": _conv_fwd_pack(blk.conv1.weight), "c1_wt": _conv_bwd_pack(blk.conv1.weight),
-                     "c2_w": _conv_fwd_pack(blk.conv2.weight), "c2_wt": _conv_bwd_pack(blk.conv2.weight)}
+                     "c1_w": pk.conv_fwd(pref + "conv1.weight"), "c1_wt": pk.conv_bwd(pref + "conv1.weight"),
+                     "c2_w": pk.conv_fwd(pref + "conv2.weight"), "c2_wt": pk.conv_bwd(pref + "conv2.weight")}
                 if blk.downsample is not None:
-                    d["ds_w"] = _conv_fwd_pack(blk.downsample["0"].weight)
-                    d["ds_wt"] = _conv_bwd_pack(blk.downsample["0"].weight)
+                    d["ds_w"] = pk.conv_fwd(pref + "downsample.0.weight")
+                    d["ds_wt"] = pk.conv_bwd(pref + "downsample.0.weight")
                 blocks.append(d)
             P["blocks"] = blocks
-            pw = m.patch_embed.weight.detach().reshape(m.embed_dim, -1)
-            P["pe_w"], P["pe_wt"] = _b(pw), _t(pw)
+            P["pe_w"], P["pe_wt"] = pk.b("patch_embed.weight"), pk.t("patch_embed.weight")
         else:
-            P["pe_w"] = _px4_pack(m.patch_embed.weight, 16)
+            P["pe_w"] = pk.px4("patch_embed.weight", 16)
         layers = []
-        for L in m.transformer.layers:
-            layers.append(dict(qkv_w=_b(L.self_attn.in_proj_weight), qkv_wt=_t(L.self_attn.in_proj_weight),
-                               out_w=_b(L.self_attn.out_proj.weight), out_wt=_t(L.self_attn.out_proj.weight),
-                               fc1_w=_b(L.linear1.weight), fc1_wt=_t(L.linear1.weight),
-                               fc2_w=_b(L.linear2.weight), fc2_wt=_t(L.linear2.weight)))
+        for i in range(m.num_layers):
+            p = f"transformer.layers.{i}."
+            layers.append(dict(qkv_w=pk.b(p + "self_attn.in_proj_weight"), qkv_wt=pk.t(p + "self_attn.in_proj_weight"),
+                               out_w=pk.b(p + "self_attn.out_proj.weight"), out_wt=pk.t(p + "self_attn.out_proj.weight"),
+                               fc1_w=pk.b(p + "linear1.weight"), fc1_wt=pk.t(p + "linear1.weight"),
+                               fc2_w=pk.b(p + "linear2.weight"), fc2_wt=pk.t(p + "linear2.weight")))
         P["layers"] = layers
-        P["h0_w"], P["h0_wt"] = _b(m.head["0"].weight), _t(m.head["0"].weight)
-        P["h3_w"] = _b(m.head["3"].weight)
-        h3t = torch.zeros(m.embed_dim // 2, 16 * ((m.num_classes + 15) // 16), dtype=BF16, device=m.pos_embed.device)
-        h3t[:, : m.num_classes] = m.head["3"].weight.detach().t().to(BF16)
-        P["h3_wt"] = h3t
-        self._pack, self._pack_key = P, key
+        P["h0_w"], P["h0_wt"] = pk.b("head.0.weight"), pk.t("head.0.weight")
+        P["h3_w"] = pk.b("head.3.weight")
+        P["h3_wt"] = pk.t_padded("head.3.weight", 16)
         return P
+
+    def _stem_blocks(self):
+        cb = self.m.cnn_backbone
+        for li in range(1, 5):
+            for bi, blk in getattr(cb, f"layer{li}").items():
+                yield f"cnn_backbone.layer{li}.{bi}.", blk
 
     # ---- buffers -----------------------------------------------------------------------------------
     def buffers(self, B: int, dev) -> dict:
@@ -396,7 +535,7 @@ class TrainEngine:
     def backward(self, dout: torch.Tensor, features_only: bool, B: int) -> torch.Tensor:
         """dout: gradient of the logits [B,C] (or of the features [B,E]); returns the flat grad buffer."""
         m = self.m
-        P = self.pack()
+        P = self._pack      # the operand copies the matching forward used
         b = self._bufs[B]
         dev = dout.device
         E, S, H, NP, C = m.embed_dim, m.num_patches + 1, m.num_heads, m.num_patches, m.num_classes
@@ -489,6 +628,7 @@ class TrainEngine:
             g("patch_embed.weight").view(E, 16, 16, 3).copy_(dw.view(E, 16, 16, 4)[..., :3])
             ops.colsum(dpatch.view(B * NP, E), g("patch_embed.bias"))
         self._finish_reduce(flat)
+        self.last_flat = flat  # vit_amd.optim.FusedAdamW reads the gradients straight from here
         return flat
 
     # ---- bucketed all-reduce overlapped with backward ------------------------------------------------
