@@ -39,6 +39,65 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 constexpr int C3_BM = 256;
 constexpr int C3_PMAX = 640;  // patch pixels a workgroup can stage (DMA pass budget)
 
+// Epilogue shared by the kernels below (same restaging as gemm.hip): accumulators go through a wave-private
+// 64-column LDS staging area so that whole 128-byte row segments reach global memory; folded-BN scale/bias,
+// residual, ReLU.  Ends the main loop with a workgroup barrier (the staging aliases patch and weight ring).
+template <int MR, int WM>
+__device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4 (&acc)[MR][4], int wave, int lane, int wm,
+                                            int wn, long m0, long m_last, int n0) {
+  const int fr = lane & 15, fq = lane >> 4;
+  __builtin_amdgcn_s_barrier();
+  constexpr int EP_PITCH = 64 * 4 + 16;
+  char* ep = smem + wave * (WM * EP_PITCH);
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i][j];
+  __syncthreads();
+  const int er = lane >> 3, ec = (lane & 7) * 8;
+  const int n = n0 + wn * 64 + ec;
+  float sc[8], bi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; bi[e] = 0.f; }
+  if (p.scale) {
+    const float4 a = *reinterpret_cast<const float4*>(p.scale + n), b = *reinterpret_cast<const float4*>(p.scale + n + 4);
+    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+  }
+  if (p.bias) {
+    const float4 a = *reinterpret_cast<const float4*>(p.bias + n), b = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
+  }
+#pragma unroll
+  for (int pass = 0; pass < WM / 8; ++pass) {
+    const int row = pass * 8 + er;
+    const long m = m0 + wm * WM + row;
+    if (m > m_last) continue;
+    float v[8];
+    {
+      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4);
+      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4 + 16);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
+    if (p.R) {
+      const uint4 r = *reinterpret_cast<const uint4*>((const bf16*)p.R + m * p.ldr + n);
+      v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+      v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
+    }
+    if (p.act == RVIT_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>((bf16*)p.C + m * p.ldc + n) = o;
+  }
+}
+
+
 // BN = 64 : 8 waves x (32 x 64) wave tiles, one patch buffer; two workgroups per CU hide each other's
 //           patch loads.
 // BN = 128: 4 x 2 waves x (64 x 64) wave tiles (0.5 instead of 0.75 LDS fragment reads per MFMA, the
@@ -228,56 +287,7 @@ _Pragma("unroll") \
 #undef ISSUE_B
 #undef ISSUE_PATCH_PASS
 
-  // ---- epilogue (same restaging as gemm.hip): wave-private 64-column staging ----------------------
-  __builtin_amdgcn_s_barrier();
-  constexpr int EP_PITCH = 64 * 4 + 16;
-  char* ep = smem + wave * (WM * EP_PITCH);
-#pragma unroll
-  for (int i = 0; i < MR; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i][j];
-  __syncthreads();
-  const int er = lane >> 3, ec = (lane & 7) * 8;
-  const int n = n0 + wn * 64 + ec;
-  float sc[8], bi[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; bi[e] = 0.f; }
-  if (p.scale) {
-    const float4 a = *reinterpret_cast<const float4*>(p.scale + n), b = *reinterpret_cast<const float4*>(p.scale + n + 4);
-    sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
-  }
-  if (p.bias) {
-    const float4 a = *reinterpret_cast<const float4*>(p.bias + n), b = *reinterpret_cast<const float4*>(p.bias + n + 4);
-    bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
-  }
-#pragma unroll
-  for (int pass = 0; pass < WM / 8; ++pass) {
-    const int row = pass * 8 + er;
-    const long m = m0 + wm * WM + row;
-    if (m > m_last) continue;
-    float v[8];
-    {
-      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4);
-      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4 + 16);
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
-    if (p.R) {
-      const uint4 r = *reinterpret_cast<const uint4*>((const bf16*)p.R + m * p.ldr + n);
-      v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
-      v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
-    }
-    if (p.act == RVIT_ACT_RELU) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    uint4 o;
-    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-    *reinterpret_cast<uint4*>((bf16*)p.C + m * p.ldc + n) = o;
-  }
+  c3_epilogue<MR, WM>(p, smem, acc, wave, lane, wm, wn, m0, m_last, n0);
 }
 
 }  // namespace
