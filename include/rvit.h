@@ -273,6 +273,20 @@ int rvit_cast_bf16(const float* x, void* out, int64_t n, void* stream);
 int rvit_transpose_batched_bf16(const void* src, void* dst, const int64_t* table, int n_entries, int64_t total_tiles,
                                 void* stream);
 
+/* Input transforms of the reference on device, from decoded uint8 frames [B,H,W,C] (C = 1 luma, 3 RGB, 4 RGBA,
+ * interleaved, 4-byte aligned base) to the fp32 NCHW tensor [B,3,out_side,out_side] the model takes:
+ *   Grayscale(3) -> Resize((resized,resized)) [-> crop out_side x out_side at crop_tl[b] = (top,left)] -> ToTensor
+ *   -> Normalize(ImageNet mean/std) [-> + noise_std * N(0,1)]
+ * (train_vit.py:722-756 train_tf / eval_tf, 557-567 AddGaussianNoise; infer.py:346-353).  Integer part bit-exact
+ * with Pillow: rgb2l, then the two-pass triangle resampling with 22-bit fixed-point coefficients.  hcoef [resized][hk]
+ * / hbounds [resized][2] = (first tap, tap count) for W -> resized, vcoef / vbounds for H -> resized, as
+ * Resample.c precompute_coeffs + normalize_coeffs_8bpc produce them (vit_amd/pipeline.py resample_tables).
+ * crop_tl may be null when resized == out_side.  tmp: scratch uint8 [B][H][out_side] owned by the caller.
+ * noise_std 0 disables the noise; otherwise element i gets a counter-based Gaussian keyed by (noise_seed, i). */
+int rvit_preprocess_u8(const uint8_t* frames, int B, int H, int W, int C, const int32_t* hcoef, const int32_t* hbounds,
+                       int hk, const int32_t* vcoef, const int32_t* vbounds, int vk, int resized, const int32_t* crop_tl,
+                       int out_side, uint8_t* tmp, float noise_std, uint64_t noise_seed, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,4 +272,11 @@ int rvit_transpose_batched_bf16(const void* src, void* dst, const int64_t* table
                                      (hipStream_t)stream);
 }
 
+int rvit_preprocess_u8(const uint8_t* frames, int B, int H, int W, int C, const int32_t* hcoef, const int32_t* hbounds,
+                       int hk, const int32_t* vcoef, const int32_t* vbounds, int vk, int resized, const int32_t* crop_tl,
+                       int out_side, uint8_t* tmp, float noise_std, uint64_t noise_seed, float* out, void* stream) {
+  return rvit_preprocess_impl(frames, B, H, W, C, hcoef, hbounds, hk, vcoef, vbounds, vk, resized, crop_tl, out_side, tmp,
+                              noise_std, noise_seed, out, (hipStream_t)stream);
+}
+
 }  // extern "C"

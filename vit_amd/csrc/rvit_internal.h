@@ -72,6 +72,9 @@ struct MxGemmArgs {
 int rvit_sumsq_impl(const float* x, long n, float* out, hipStream_t st);  // optim.hip
 int rvit_adamw_impl(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                     float wd, int step, const float* gnorm_sq, float max_norm, bf16* mirror, hipStream_t st);
+int rvit_preprocess_impl(const uint8_t* img, int B, int H, int W, int C, const int* hcoef, const int* hbounds, int hk,
+                         const int* vcoef, const int* vbounds, int vk, int resized, const int* crop, int out_side,
+                         uint8_t* tmp, float noise_std, uint64_t noise_seed, float* out, hipStream_t st);  // preproc.hip
 int rvit_cast_bf16_impl(const float* x, bf16* out, long n, hipStream_t st);
 int rvit_transpose_batched_impl(const bf16* src, bf16* dst, const long* table, int n_entries, long total_tiles,
                                 hipStream_t st);

@@ -706,3 +706,31 @@ def transpose_batched(src: torch.Tensor, dst: torch.Tensor, table) -> torch.Tens
         check(_lib.load().rvit_transpose_batched_bf16(_ptr(src), _ptr(dst), _ptr(tab), n, tiles, _stream()),
               "rvit_transpose_batched_bf16")
     return dst
+
+
+def preprocess_u8(frames: torch.Tensor, tables_h, tables_v, resized: int, out: torch.Tensor, tmp: torch.Tensor,
+                  crop_tl: Optional[torch.Tensor] = None, noise_std: float = 0.0, noise_seed: int = 0) -> torch.Tensor:
+    """uint8 frames [B,H,W,C] (or [B,H,W]) -> normalised fp32 [B,3,S,S] (rvit_preprocess_u8).  tables_* =
+    (ksize, bounds int32 [resized,2], coefficients int32 [resized,ksize]) on the device."""
+    _need_cuda(frames, out, tmp, crop_tl, tables_h[1], tables_h[2], tables_v[1], tables_v[2])
+    if frames.dtype != torch.uint8 or not frames.is_contiguous() or frames.dim() not in (3, 4):
+        raise ValueError("preprocess_u8: contiguous uint8 [B,H,W,C] or [B,H,W] frames expected")
+    B, H, W = frames.shape[:3]
+    C = frames.shape[3] if frames.dim() == 4 else 1
+    S = out.shape[-1]
+    if out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != (B, 3, S, S):
+        raise ValueError("preprocess_u8: out must be contiguous float32 [B,3,S,S]")
+    if tmp.dtype != torch.uint8 or not tmp.is_contiguous() or tmp.numel() < B * H * S:
+        raise ValueError("preprocess_u8: tmp must hold B*H*S bytes")
+    for (ks, bounds, coef), n_in in ((tables_h, W), (tables_v, H)):
+        if bounds.dtype != torch.int32 or coef.dtype != torch.int32 or tuple(bounds.shape) != (resized, 2) \
+                or tuple(coef.shape) != (resized, ks) or not bounds.is_contiguous() or not coef.is_contiguous():
+            raise ValueError("preprocess_u8: malformed resampling tables")
+    if crop_tl is not None and (crop_tl.dtype != torch.int32 or tuple(crop_tl.shape) != (B, 2) or not crop_tl.is_contiguous()):
+        raise ValueError("preprocess_u8: crop_tl must be int32 [B,2] (top, left)")
+    with _Span("preprocess_u8", 0, frames.numel() + 2 * B * H * S + out.numel() * 4):
+        check(_lib.load().rvit_preprocess_u8(_ptr(frames), B, H, W, C, _ptr(tables_h[2]), _ptr(tables_h[1]), tables_h[0],
+                                             _ptr(tables_v[2]), _ptr(tables_v[1]), tables_v[0], resized, _ptr(crop_tl), S,
+                                             _ptr(tmp), float(noise_std), int(noise_seed) & ((1 << 64) - 1), _ptr(out),
+                                             _stream()), "rvit_preprocess_u8")
+    return out
