@@ -8,6 +8,8 @@ dev = torch.device("cuda:0")
 m = CNNViTHybrid(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18")
 m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, 0))
 m = m.to(dev).eval()
+if os.environ.get("RVIT_GRAPHS"):
+    m.set_graph_capture(int(os.environ["RVIT_GRAPHS"]))
 for B in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,8,64,512").split(",")]:
     x = torch.randn(B, 3, 224, 224, device=dev)
     with torch.no_grad():

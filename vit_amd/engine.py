@@ -54,6 +54,7 @@ class Engine:
         # (e4m3 + E8M0 per 32) weights and activations; LayerNorm, softmax, the residual stream, the stem, the
         # patch embedding and the head stay bf16 / fp32 (BASELINE.json configs[4])
         self.precision = "bf16"
+        self.graph_max_batch = 0
 
     def set_precision(self, precision: str) -> None:
         if precision not in ("bf16", "mxfp8"):
@@ -267,11 +268,48 @@ class Engine:
         ops.gemm(b["h0"], P["h3_w"], logits, bias=P["h3_b"])
         return logits
 
+    # ---- hipGraph replay for launch-bound batch sizes ---------------------------------------------
+    def set_graph_capture(self, max_batch: int) -> None:
+        """Forwards of at most `max_batch` frames are captured once per (batch, output kind) into a HIP graph
+        and replayed: ~65 kernel launches become one graph launch (B=1 is launch-bound).  0 disables."""
+        self.graph_max_batch = int(max_batch)
+
+    @torch.no_grad()
+    def _infer_graph(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
+        P = self.pack()
+        if x.device != P["device"]:
+            raise RuntimeError(f"input on {x.device} but model on {P['device']}")
+        B = x.shape[0]
+        graphs = P.setdefault("_graphs", {})     # tied to this weight pack: a re-pack drops them
+        rec = graphs.get((B, features_only))
+        if rec is None:
+            static_in = torch.empty(B, 3, 224, 224, dtype=torch.float32, device=x.device)
+            static_in.copy_(x)
+            cur = torch.cuda.current_stream(x.device)
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):        # warm-up off the capture: buffers, lazy kernel attributes
+                for _ in range(2):
+                    self.infer(static_in, features_only)
+            cur.wait_stream(side)
+            bufs = self.buffers(B, x.device)     # keep them alive even if the small buffer cache evicts them
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.infer(static_in, features_only)
+            rec = (graph, static_in, static_out, bufs)
+            if len(graphs) >= 8:
+                graphs.pop(next(iter(graphs)))
+            graphs[(B, features_only)] = rec
+        graph, static_in, static_out, _ = rec
+        static_in.copy_(x)
+        graph.replay()
+        return static_out.clone()
+
     def run(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
         m = self.m
-        if m.training and torch.is_grad_enabled():
-            raise NotImplementedError("training forward/backward through librvit is not wired up yet")
         if m.training:
             raise RuntimeError("call model.eval() for inference: BatchNorm batch statistics and dropout of "
                                "train mode are only available on the training path")
+        if 0 < x.shape[0] <= self.graph_max_batch and ops._PROF is None and not torch.cuda.is_current_stream_capturing():
+            return self._infer_graph(x, features_only)
         return self.infer(x, features_only)

@@ -228,6 +228,10 @@ class CNNViTHybrid(nn.Module):
         """'bf16' (default) or 'mxfp8': encoder Linears on the block-scaled fp8 MFMA (eval mode only)."""
         self.engine.set_precision(precision)
 
+    def set_graph_capture(self, max_batch: int = 16) -> None:
+        """Replay eval-mode forwards of up to `max_batch` frames from a captured HIP graph (0 disables)."""
+        self.engine.set_graph_capture(max_batch)
+
     def set_data_parallel(self, process_group=None, bucket_mb: float = 8.0) -> None:
         """Average gradients over `process_group` (RCCL) in buckets overlapped with backward."""
         self.train_engine.set_data_parallel(process_group, bucket_mb)
