@@ -287,6 +287,24 @@ int rvit_preprocess_u8(const uint8_t* frames, int B, int H, int W, int C, const 
                        int hk, const int32_t* vcoef, const int32_t* vbounds, int vk, int resized, const int32_t* crop_tl,
                        int out_side, uint8_t* tmp, float noise_std, uint64_t noise_seed, float* out, void* stream);
 
+/* One time step of nn.LSTM (batch_first, 1 or 2 directions: pass the *_r set or nulls), fp32, torch gate order
+ * i,f,g,o: the temporal encoder of the sequence model (train_vit.py:188-229 TemporalEncoder, infer.py:186-227).
+ * Call with step = 0 .. T-1 in order.  x [B,T,In]; weights as nn.LSTM stores them (w_ih [4H,In], w_hh [4H,H],
+ * biases [4H]); out [B,T,ndir*H]: the forward direction writes time `step`, the reverse direction time
+ * T-1-step, each reading its previous h from `out` (zero state at step 0); c [ndir,B,H] is the running cell
+ * state.  gates [B,T,ndir,4H] (activated) and cseq [B,T,ndir,H] are saved for the backward pass when non-null
+ * (both or neither).  H % 8 == 0, In % 4 == 0. */
+int rvit_lstm_step_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                       const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* out,
+                       float* c, float* gates, float* cseq, int B, int T, int In, int H, int step, void* stream);
+
+/* Backward of one time step (autograd of nn.LSTM, train_vit.py:939); call with step = T-1 .. 0.  dout [B,T,ndir*H]
+ * = gradient of `out`; w_hh_t = W_hh^T [H,4H] per direction; dgates [B,T,ndir,4H] receives the pre-activation
+ * gradients of this step (and is read at the step processed before); dc [ndir,B,H] carries the cell-state
+ * gradient.  Weight, bias and input gradients follow from dgates with plain GEMMs (rvit_wgrad_bf16 etc.). */
+int rvit_lstm_step_bwd(const float* dout, const float* w_hh_t, const float* w_hh_t_r, const float* gates,
+                       const float* cseq, float* dgates, float* dc, int B, int T, int H, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

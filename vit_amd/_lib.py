@@ -58,6 +58,8 @@ SIGNATURES = {
     "rvit_sumsq_f32": ([P, L, P, P], c_int),
     "rvit_adamw_step": ([P, P, P, P, L, F, F, F, F, F, I, P, F, P, P], c_int),
     "rvit_cast_bf16": ([P, P, L, P], c_int),
+    "rvit_lstm_step_fwd": ([P] * 13 + [I] * 5 + [P], c_int),
+    "rvit_lstm_step_bwd": ([P] * 7 + [I] * 4 + [P], c_int),
     "rvit_preprocess_u8": ([P, I, I, I, I, P, P, I, P, P, I, I, P, I, P, F, U64, P, P], c_int),
     "rvit_transpose_batched_bf16": ([P, P, P, I, L, P], c_int),
     "rvit_bn_stats": ([P, L, I, P, P], c_int),

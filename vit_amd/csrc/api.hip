@@ -279,4 +279,17 @@ int rvit_preprocess_u8(const uint8_t* frames, int B, int H, int W, int C, const 
                               noise_std, noise_seed, out, (hipStream_t)stream);
 }
 
+int rvit_lstm_step_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                       const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* out,
+                       float* c, float* gates, float* cseq, int B, int T, int In, int H, int step, void* stream) {
+  const float* w[8] = {w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r};
+  return rvit_lstm_step_fwd_impl(x, w, out, c, gates, cseq, B, T, In, H, step, w_ih_r ? 2 : 1, (hipStream_t)stream);
+}
+
+int rvit_lstm_step_bwd(const float* dout, const float* w_hh_t, const float* w_hh_t_r, const float* gates,
+                       const float* cseq, float* dgates, float* dc, int B, int T, int H, int step, void* stream) {
+  return rvit_lstm_step_bwd_impl(dout, w_hh_t, w_hh_t_r, gates, cseq, dgates, dc, B, T, H, step, w_hh_t_r ? 2 : 1,
+                                 (hipStream_t)stream);
+}
+
 }  // extern "C"

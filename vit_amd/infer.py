@@ -12,7 +12,7 @@ Differences, all deliberate:
     (train_vit.py:996-1019: model / classes / model_config / metadata) holds only tensors and plain
     containers, nothing needs to be unpickled;
   * predict_batch / predict_folder batch the images through one forward (the reference loops).
-The sequence model (mode == "sequence") is outside this round's scope and raises.
+Checkpoints with mode == "sequence" load as vit_amd.sequence.CNNViTSequence (streaming: StreamingClassifier there).
 """
 from __future__ import annotations
 
@@ -41,7 +41,7 @@ class PredictionResult:  # infer.py:48-55
     raw_logits: Optional[np.ndarray] = None
 
 
-def load_model(checkpoint_path: str, device: torch.device) -> Tuple[CNNViTHybrid, list, dict]:
+def load_model(checkpoint_path: str, device: torch.device) -> Tuple[torch.nn.Module, list, dict]:
     """(model in eval mode on `device`, class names, metadata) from a reference-layout checkpoint."""
     if not os.path.exists(checkpoint_path):
         raise FileNotFoundError(f"Checkpoint not found: {checkpoint_path}")
@@ -56,11 +56,13 @@ def load_model(checkpoint_path: str, device: torch.device) -> Tuple[CNNViTHybrid
     metadata = dict(ckpt.get("metadata", {"confidence_threshold": 0.5, "trained_at": "unknown",
                                           "config_hash": "unknown"}))
     mode = config.get("mode", "single")
-    if mode != "single":
-        raise NotImplementedError(f"checkpoint mode {mode!r}: only the single-frame CNNViTHybrid is built")
-    model = CNNViTHybrid(num_classes=config["num_classes"], backbone=config.get("backbone", "resnet18"),
-                         embed_dim=config["embed_dim"], num_heads=config["num_heads"],
-                         num_layers=config["num_layers"], dropout=config["dropout"])
+    if mode == "sequence":     # infer.py:301-302
+        from .sequence import CNNViTSequence
+        model = CNNViTSequence(num_classes=config["num_classes"], config=config)
+    else:
+        model = CNNViTHybrid(num_classes=config["num_classes"], backbone=config.get("backbone", "resnet18"),
+                             embed_dim=config["embed_dim"], num_heads=config["num_heads"],
+                             num_layers=config["num_layers"], dropout=config["dropout"])
     model.load_state_dict(ckpt["model"])
     model.to(device)
     model.eval()
