@@ -24,7 +24,7 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
 }
 
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int total_pairs, int S, int H,
                                                        long ldq, long ldo, float scale_log2e, float scale,
                                                        DropKey dk) {
@@ -204,8 +204,12 @@ __device__ __forceinline__ int du_off(int row, int ch) {
   return row * 128 + ((ch ^ g) << 4);
 }
 
+// Waves per workgroup of the backward kernel: its four LDS images allow only one workgroup per CU once S > 128
+// (NKB >= 5), so those cases run 8 waves (two per SIMD, one round over the <= 8 key / query blocks).
+template <int NKB> constexpr int bwd_waves() { return NKB >= 5 ? 8 : 4; }
+
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+__global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
                                                        const bf16* __restrict__ dO, const float* __restrict__ lse,
                                                        bf16* __restrict__ dqkv, int total_pairs, int S, int H,
                                                        long ldq, long ldo, long lddo, long lddq, float scale,
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
     char* sD = sV + TILE;
     float* sLse = reinterpret_cast<float*>(sD + TILE);
     float* sDel = sLse + SP;
-    for (int id = t; id < SP * 8; id += 256) {
+    for (int id = t; id < SP * 8; id += 64 * bwd_waves<NKB>()) {
       const int row = id >> 3, c = id & 7;
       const bool ok = pv && row < S;
       const long tok = (long)b * S + row;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
   const int tr_byte = (lane & 1) * 8;
 
   // ================================ pass A: dK, dV ================================================
-  for (int ki = wave; ki < PAIRS * NKB; ki += 4) {
+  for (int ki = wave; ki < PAIRS * NKB; ki += bwd_waves<NKB>()) {
     const int pi = ki / NKB, kb = ki - pi * NKB;
     const int pair = pair0 + pi;
     if (pair >= total_pairs || kb * 32 >= S) continue;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
   }
 
   // ================================ pass B: dQ =====================================================
-  for (int qi = wave; qi < PAIRS * NKB; qi += 4) {
+  for (int qi = wave; qi < PAIRS * NKB; qi += bwd_waves<NKB>()) {
     const int pi = qi / NKB, qb = qi - pi * NKB;
     const int pair = pair0 + pi;
     if (pair >= total_pairs || qb * 32 >= S) continue;
@@ -456,7 +460,7 @@ int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float*
   }
   const int total = B * H;
   const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
-  hipLaunchKernelGGL((attn_bwd_kernel<NKB>), dim3(grid), dim3(256), LDS, st, qkv, O, dO, lse, dqkv, total, S, H, ldq,
+  hipLaunchKernelGGL((attn_bwd_kernel<NKB>), dim3(grid), dim3(64 * bwd_waves<NKB>()), LDS, st, qkv, O, dO, lse, dqkv, total, S, H, ldq,
                      ldo, lddo, lddq, scale, dk);
   RVIT_CHECK_LAUNCH("attn_bwd");
   return RVIT_OK;
