@@ -60,6 +60,38 @@ def cpu_baseline(sd, seconds=20.0, batch=8):
                       f"same weights/inputs generator"}
 
 
+def cpu_train_baseline(sd, cfg, steps=4, batch=32, seconds=25.0):
+    """The oracle's training step on the host cores beside the `train` figure: forward (train mode) + label-smoothed
+    CE + backward + clip + AdamW at the reference's batch size 32 (train_vit.py:407-437,505-515); SURVEY.md §8d."""
+    from oracle.ref_model import CNNViTHybridRef
+    from vit_amd.synth import micro_doppler_batch
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(cores)
+    ref = CNNViTHybridRef(**cfg)
+    if sd is not None:
+        ref.load_state_dict(sd)
+    ref.train()
+    x = micro_doppler_batch(batch, seed=99)
+    y = torch.randint(0, cfg["num_classes"], (batch,), generator=torch.Generator().manual_seed(0))
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=0.05)
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.05)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        crit(ref(x), y).backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step()
+
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < steps and time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * batch / dt, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} optimiser steps of batch {batch} (fp32, torch {torch.__version__}), same model / loss / optimiser"}
+
+
 def _say(rank, msg):
     if os.environ.get("RVIT_BENCH_VERBOSE"):
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
@@ -138,7 +170,10 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
     if rank != 0:
         return None
     sps = world * B * args.train_steps / dt
-    return {"metric": "train_samples_per_sec", "value": round(sps, 1), "unit": "samples/s",
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and cfg["embed_dim"] <= 256:   # the R model only: ViT-B steps take minutes on a CPU
+        cpu = cpu_train_baseline(sd, cfg)
+    return {"metric": "train_samples_per_sec", "cpu_baseline": cpu, "value": round(sps, 1), "unit": "samples/s",
             "ms_per_step": round(dt / args.train_steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_host / args.train_steps * 1e3, 3), "steps": args.train_steps,
             "batch_per_gpu": B,
