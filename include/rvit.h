@@ -305,6 +305,16 @@ int rvit_lstm_step_fwd(const float* x, const float* w_ih, const float* w_hh, con
 int rvit_lstm_step_bwd(const float* dout, const float* w_hh_t, const float* w_hh_t_r, const float* gates,
                        const float* cseq, float* dgates, float* dc, int B, int T, int H, int step, void* stream);
 
+/* nn.GRU counterparts of the two LSTM entry points (TemporalEncoder model_type='gru', train_vit.py:207-211):
+ * gate order r,z,n, weights [3H,In] / [3H,H].  saved [B,T,ndir,4H] = (r, z, n, W_hn h + b_hn), null in inference.
+ * Backward: w_hh_t = W_hh^T [H,3H]; `out` is the forward's output sequence (h_prev); dgates [B,T,ndir,6H] =
+ * input-side (dr,dz,dn) then hidden-side (dr,dz,dn*r) pre-activation gradients; dh_carry [ndir,B,H]. */
+int rvit_gru_step_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                      const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* out,
+                      float* saved, int B, int T, int In, int H, int step, void* stream);
+int rvit_gru_step_bwd(const float* dout, const float* w_hh_t, const float* w_hh_t_r, const float* saved, const float* out,
+                      float* dgates, float* dh_carry, int B, int T, int H, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,11 +19,12 @@ from .ref_model import CNNViTHybridRef
 
 
 class TemporalEncoderRef(nn.Module):       # train_vit.py:188-229
-    def __init__(self, input_dim, hidden_dim=256, num_layers=2, dropout=0.3, bidirectional=True):
+    def __init__(self, input_dim, hidden_dim=256, num_layers=2, dropout=0.3, bidirectional=True, model_type="lstm"):
         super().__init__()
         self.bidirectional, self.hidden_dim = bidirectional, hidden_dim
-        self.rnn = nn.LSTM(input_dim, hidden_dim, num_layers=num_layers, batch_first=True,
-                           dropout=dropout if num_layers > 1 else 0, bidirectional=bidirectional)
+        cls = {"lstm": nn.LSTM, "gru": nn.GRU}[model_type]                       # train_vit.py:202-213
+        self.rnn = cls(input_dim, hidden_dim, num_layers=num_layers, batch_first=True,
+                       dropout=dropout if num_layers > 1 else 0, bidirectional=bidirectional)
         self.output_dim = hidden_dim * (2 if bidirectional else 1)
 
     def forward(self, x):
@@ -41,7 +42,8 @@ class CNNViTSequenceRef(nn.Module):        # train_vit.py:232-318
                                                dropout=config["dropout"])
         self.temporal_encoder = TemporalEncoderRef(config["embed_dim"], config.get("temporal_hidden", 256),
                                                    config.get("temporal_layers", 2), config.get("temporal_dropout", 0.3),
-                                                   config.get("temporal_bidirectional", True))
+                                                   config.get("temporal_bidirectional", True),
+                                                   config.get("temporal_model", "lstm"))
         d = self.temporal_encoder.output_dim
         self.classifier = nn.Sequential(nn.Linear(d, d // 2), nn.GELU(), nn.Dropout(config.get("classifier_dropout", 0.4)),
                                         nn.Linear(d // 2, num_classes))

@@ -31,10 +31,18 @@ def test_state_dict_names_and_shapes_match_reference_modules():
     assert [n for n, _ in mine.temporal_encoder.rnn.named_parameters()] == [n for n, _ in ref.temporal_encoder.rnn.named_parameters()]
 
 
+def test_gru_state_dict_matches_nn_gru():
+    from vit_amd.sequence import CNNViTSequence
+    cfg = dict(CFG, temporal_model="gru")
+    mine, ref = CNNViTSequence(11, cfg), rs.CNNViTSequenceRef(11, cfg)
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    mine.load_state_dict(ref.state_dict())
+
+
 def test_unsupported_variants_are_loud():
     from vit_amd.sequence import CNNViTSequence, TemporalEncoder
     with pytest.raises(NotImplementedError):
-        TemporalEncoder(128, model_type="gru")
+        TemporalEncoder(130, hidden_dim=64)                      # input width not a multiple of 4
     with pytest.raises(ValueError):
         TemporalEncoder(128, model_type="rnn")
     m = CNNViTSequence(11, CFG)

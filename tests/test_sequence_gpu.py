@@ -42,8 +42,25 @@ def test_temporal_encoder_forward_fp32(dev, bidir, layers, B, T):
     assert torch.allclose(got, want, atol=2e-5, rtol=1e-4), (got - want).abs().max().item()
 
 
-def test_temporal_head_eval_and_gradients(dev):
-    mine, ref = _pair(dev)
+@pytest.mark.parametrize("bidir,layers,B,T", [(True, 2, 3, 5), (False, 1, 2, 1), (False, 2, 17, 4)])
+def test_gru_encoder_forward_fp32(dev, bidir, layers, B, T):
+    from vit_amd.sequence import TemporalEncoder
+    torch.manual_seed(2)
+    ref = rs.TemporalEncoderRef(32, 24, layers, 0.3, bidir, "gru").eval()
+    mine = TemporalEncoder(32, 24, layers, 0.3, bidir, "gru")
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev).eval()
+    x = torch.randn(B, T, 32)
+    with torch.no_grad():
+        want, got = ref(x), mine(x.to(dev)).cpu()
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-4), (got - want).abs().max().item()
+
+
+@pytest.mark.parametrize("model_type", ["lstm", "gru"])
+def test_temporal_head_eval_and_gradients(dev, model_type):
+    cfg = dict(CFG, temporal_model=model_type)
+    mine, ref = _pair(dev, cfg)
+    assert mine.temporal_encoder.model_type == model_type and type(ref.temporal_encoder.rnn).__name__.lower() == model_type
     B, T, E = 5, 4, CFG["embed_dim"]
     f = torch.randn(B, T, E)
     y = torch.tensor([0, 3, 5, 10, 2])
@@ -54,7 +71,7 @@ def test_temporal_head_eval_and_gradients(dev):
         got = mine.forward_temporal_only(f.to(dev)).cpu()
     assert torch.allclose(got, want, atol=2e-2, rtol=2e-2), (got - want).abs().max().item()
     # gradients with every dropout probability at 0 (exact same function on both sides)
-    cfg0 = dict(CFG, temporal_dropout=0.0, classifier_dropout=0.0)
+    cfg0 = dict(cfg, temporal_dropout=0.0, classifier_dropout=0.0)
     mine, ref = _pair(dev, cfg0)
     mine.train(); ref.train()
     fr = f.clone().requires_grad_(True)

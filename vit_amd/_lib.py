@@ -60,6 +60,8 @@ SIGNATURES = {
     "rvit_cast_bf16": ([P, P, L, P], c_int),
     "rvit_lstm_step_fwd": ([P] * 13 + [I] * 5 + [P], c_int),
     "rvit_lstm_step_bwd": ([P] * 7 + [I] * 4 + [P], c_int),
+    "rvit_gru_step_fwd": ([P] * 11 + [I] * 5 + [P], c_int),
+    "rvit_gru_step_bwd": ([P] * 7 + [I] * 4 + [P], c_int),
     "rvit_preprocess_u8": ([P, I, I, I, I, P, P, I, P, P, I, I, P, I, P, F, U64, P, P], c_int),
     "rvit_transpose_batched_bf16": ([P, P, P, I, L, P], c_int),
     "rvit_bn_stats": ([P, L, I, P, P], c_int),

@@ -292,4 +292,17 @@ int rvit_lstm_step_bwd(const float* dout, const float* w_hh_t, const float* w_hh
                                  (hipStream_t)stream);
 }
 
+int rvit_gru_step_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                      const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* out,
+                      float* saved, int B, int T, int In, int H, int step, void* stream) {
+  const float* w[8] = {w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r};
+  return rvit_gru_step_fwd_impl(x, w, out, saved, B, T, In, H, step, w_ih_r ? 2 : 1, (hipStream_t)stream);
+}
+
+int rvit_gru_step_bwd(const float* dout, const float* w_hh_t, const float* w_hh_t_r, const float* saved, const float* out,
+                      float* dgates, float* dh_carry, int B, int T, int H, int step, void* stream) {
+  return rvit_gru_step_bwd_impl(dout, w_hh_t, w_hh_t_r, saved, out, dgates, dh_carry, B, T, H, step, w_hh_t_r ? 2 : 1,
+                                (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,4 +1,4 @@
-// LSTM time step, forward and backward, both directions in one launch: the temporal encoder of the reference's
+// LSTM / GRU time step, forward and backward, both directions in one launch: the temporal encoder of the reference's
 // sequence model (nn.LSTM(E, 256, num_layers=2, batch_first, bidirectional), train_vit.py:188-229,
 // infer.py:186-227) and its autograd (train_vit.py:939).  torch gate order i, f, g, o:
 //   pre = W_ih x_t + b_ih + W_hh h_prev + b_hh;  i,f,o = sigmoid, g = tanh;  c = f*c_prev + i*g;  h = o*tanh(c)
@@ -171,6 +171,150 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restr
   }
 }
 
+// ---- GRU (model_type='gru' of TemporalEncoder, train_vit.py:207-211) ----------------------------------------
+//   r = sigmoid(W_ir x + b_ir + W_hr h + b_hr);  z = sigmoid(W_iz x + b_iz + W_hz h + b_hz)
+//   hn = W_hn h + b_hn;  n = tanh(W_in x + b_in + r * hn);  h' = (1 - z) * n + z * h
+// Same workgroup shape as the LSTM step: 32 dot-product rows per 8 hidden units = r and z over [x | h], the
+// n gate's x part and its h part separately (r multiplies only the latter).  saved[b,t,dir,4H] = (r, z, n, hn).
+__global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restrict__ x, LstmDir d0, LstmDir d1,
+                                                           float* __restrict__ out, float* __restrict__ saved, int B,
+                                                           int T, int In, int H, int s, int ndir) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = In + H;
+  float* xh = sm;
+  float* pre = sm + LS_BC * K;
+  const int dir = blockIdx.y;
+  const LstmDir w = dir ? d1 : d0;
+  const int t = dir ? T - 1 - s : s, tp = dir ? t + 1 : t - 1;
+  const int j0 = blockIdx.x * LS_JB;
+  const int r = threadIdx.x >> 3, p = threadIdx.x & 7;
+  const int q = r >> 3, jj = r & 7;
+  const int grow = (q == 3 ? 2 : q) * H + j0 + jj;     // row of the [3H, .] matrices
+  const float* wi = w.w_ih + (long)grow * In;
+  const float* wh = w.w_hh + (long)grow * H;
+  const int k_lo = q == 3 ? In : 0, k_hi = q == 2 ? In : K;
+  const int OW = ndir * H;
+  for (int b0 = 0; b0 < B; b0 += LS_BC) {
+    const int nb = B - b0 < LS_BC ? B - b0 : LS_BC;
+    __syncthreads();
+    for (int i = threadIdx.x; i < LS_BC * K; i += 256) {
+      const int bb = i / K, k = i - bb * K;
+      float v = 0.f;
+      if (bb < nb) {
+        if (k < In) v = x[((long)(b0 + bb) * T + t) * In + k];
+        else if (s > 0) v = out[((long)(b0 + bb) * T + tp) * OW + dir * H + (k - In)];
+      }
+      xh[i] = v;
+    }
+    __syncthreads();
+    float acc[LS_BC];
+#pragma unroll
+    for (int bb = 0; bb < LS_BC; ++bb) acc[bb] = 0.f;
+    for (int k = k_lo + p * 4; k < k_hi; k += 32) {
+      const float4 wv = k < In ? *reinterpret_cast<const float4*>(wi + k) : *reinterpret_cast<const float4*>(wh + (k - In));
+#pragma unroll
+      for (int bb = 0; bb < LS_BC; ++bb) {
+        const float4 xv = *reinterpret_cast<const float4*>(xh + bb * K + k);
+        acc[bb] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < LS_BC; ++bb) {
+      float v = acc[bb];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+      if (p == 0) pre[r * LS_BC + bb] = v + (q != 3 ? w.b_ih[grow] : 0.f) + (q != 2 ? w.b_hh[grow] : 0.f);
+    }
+    __syncthreads();
+    if (threadIdx.x < LS_JB * LS_BC) {
+      const int bb = threadIdx.x / LS_JB, j = threadIdx.x % LS_JB;
+      if (bb < nb) {
+        const int b = b0 + bb, hj = j0 + j;
+        const float gr = ls_sigmoid(pre[(0 * 8 + j) * LS_BC + bb]), gz = ls_sigmoid(pre[(1 * 8 + j) * LS_BC + bb]);
+        const float hn = pre[(3 * 8 + j) * LS_BC + bb];
+        const float gn = tanhf(pre[(2 * 8 + j) * LS_BC + bb] + gr * hn);
+        const float hp = xh[bb * K + In + hj];
+        out[((long)b * T + t) * OW + dir * H + hj] = (1.f - gz) * gn + gz * hp;
+        if (saved) {
+          float* g = saved + (((long)b * T + t) * ndir + dir) * 4 * H + hj;
+          g[0] = gr; g[H] = gz; g[2 * H] = gn; g[3 * H] = hn;
+        }
+      }
+    }
+  }
+}
+
+// Backward GRU step (s = T-1 .. 0).  dh = dout[b,t] + dhd (direct path dh_next * z_next, carried in `dhd`
+// [ndir,B,H]) + dGh[b,t_next] . W_hh.  dG[b,t,dir,6H] = input-side gate gradients (dr, dz, dn) then hidden-side
+// (dr, dz, dn * r); whh_t = W_hh^T [H,3H].
+__global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restrict__ dout, LstmDir d0, LstmDir d1,
+                                                           const float* __restrict__ saved,
+                                                           const float* __restrict__ out, float* __restrict__ dG,
+                                                           float* __restrict__ dhd, int B, int T, int H, int s,
+                                                           int ndir) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int G3 = 3 * H;
+  float* dgn = sm;                      // [LS_BC][3H]: hidden-side dG of the step processed before
+  float* dhr = sm + LS_BC * G3;         // [LS_JB][LS_BC]
+  const int dir = blockIdx.y;
+  const float* whh_t = (dir ? d1 : d0).w_hh;
+  const int t = dir ? T - 1 - s : s;
+  const int tn = dir ? t - 1 : t + 1, tpv = dir ? t + 1 : t - 1;
+  const int j0 = blockIdx.x * LS_JB;
+  const int jj = threadIdx.x >> 5, p = threadIdx.x & 31;
+  const float* wr = whh_t + (long)(j0 + jj) * G3;
+  const int OW = ndir * H;
+  for (int b0 = 0; b0 < B; b0 += LS_BC) {
+    const int nb = B - b0 < LS_BC ? B - b0 : LS_BC;
+    __syncthreads();
+    if (s < T - 1) {
+      for (int i = threadIdx.x; i < LS_BC * G3; i += 256) {
+        const int bb = i / G3, k = i - bb * G3;
+        dgn[i] = bb < nb ? dG[(((long)(b0 + bb) * T + tn) * ndir + dir) * 2 * G3 + G3 + k] : 0.f;
+      }
+      __syncthreads();
+      float acc[LS_BC];
+#pragma unroll
+      for (int bb = 0; bb < LS_BC; ++bb) acc[bb] = 0.f;
+      for (int k = p * 4; k < G3; k += 128) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+        for (int bb = 0; bb < LS_BC; ++bb) {
+          const float4 gv = *reinterpret_cast<const float4*>(dgn + bb * G3 + k);
+          acc[bb] += wv.x * gv.x + wv.y * gv.y + wv.z * gv.z + wv.w * gv.w;
+        }
+      }
+#pragma unroll
+      for (int bb = 0; bb < LS_BC; ++bb) {
+        float v = acc[bb];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+        if (p == 0) dhr[jj * LS_BC + bb] = v;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x < LS_JB * LS_BC) {
+      const int bb = threadIdx.x / LS_JB, j = threadIdx.x % LS_JB;
+      if (bb < nb) {
+        const int b = b0 + bb, hj = j0 + j;
+        const long gt = ((long)b * T + t) * ndir + dir;
+        const float* g = saved + gt * 4 * H + hj;
+        const float gr = g[0], gz = g[H], gn = g[2 * H], hn = g[3 * H];
+        const float hp = s > 0 ? out[((long)b * T + tpv) * OW + dir * H + hj] : 0.f;
+        float* carry = dhd + ((long)dir * B + b) * H + hj;
+        float dh = dout[((long)b * T + t) * OW + dir * H + hj];
+        if (s < T - 1) dh += *carry + dhr[j * LS_BC + bb];
+        const float dn = dh * (1.f - gz) * (1.f - gn * gn);
+        const float dz = dh * (hp - gn) * gz * (1.f - gz);
+        const float dr = dn * hn * gr * (1.f - gr);
+        float* o = dG + gt * 2 * G3 + hj;
+        o[0] = dr; o[H] = dz; o[2 * H] = dn;
+        o[G3] = dr; o[G3 + H] = dz; o[G3 + 2 * H] = dn * gr;
+        *carry = dh * gz;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int lstm_check(int B, int T, int In, int H, int s, int ndir) {
@@ -207,5 +351,36 @@ int rvit_lstm_step_bwd_impl(const float* dout, const float* whh_t0, const float*
   hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(H / LS_JB, ndir), dim3(256), lds, st, dout, d0, d1, gates, cseq, dG, dc,
                      B, T, H, s, ndir);
   RVIT_CHECK_LAUNCH("lstm_step_bwd");
+  return RVIT_OK;
+}
+
+int rvit_gru_step_fwd_impl(const float* x, const float* const* w, float* out, float* saved, int B, int T, int In, int H,
+                           int s, int ndir, hipStream_t st) {
+  if (int e = lstm_check(B, T, In, H, s, ndir)) return e;
+  RVIT_CHECK_ARG(x && w && out, "gru_step_fwd: null pointer");
+  for (int i = 0; i < 4 * ndir; ++i) RVIT_CHECK_ARG(w[i] && rvit_aligned16(w[i]), "gru_step_fwd: weight %d null or unaligned", i);
+  RVIT_CHECK_ARG(rvit_aligned16(x) && rvit_aligned16(out), "gru_step_fwd: alignment");
+  const LstmDir d0{w[0], w[1], w[2], w[3]};
+  const LstmDir d1 = ndir == 2 ? LstmDir{w[4], w[5], w[6], w[7]} : d0;
+  const size_t lds = (size_t)(LS_BC * (In + H) + 32 * LS_BC) * sizeof(float);
+  RVIT_CHECK_ARG(lds <= 64 * 1024, "gru_step_fwd: In + H = %d too wide for the LDS vector buffer", In + H);
+  hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(H / LS_JB, ndir), dim3(256), lds, st, x, d0, d1, out, saved, B, T, In, H,
+                     s, ndir);
+  RVIT_CHECK_LAUNCH("gru_step_fwd");
+  return RVIT_OK;
+}
+
+int rvit_gru_step_bwd_impl(const float* dout, const float* whh_t0, const float* whh_t1, const float* saved,
+                           const float* out, float* dG, float* dhd, int B, int T, int H, int s, int ndir,
+                           hipStream_t st) {
+  if (int e = lstm_check(B, T, 4, H, s, ndir)) return e;
+  RVIT_CHECK_ARG(dout && whh_t0 && (ndir == 1 || whh_t1) && saved && out && dG && dhd, "gru_step_bwd: null pointer");
+  RVIT_CHECK_ARG(rvit_aligned16(whh_t0) && rvit_aligned16(whh_t1) && rvit_aligned16(dG), "gru_step_bwd: alignment");
+  const LstmDir d0{nullptr, whh_t0, nullptr, nullptr}, d1{nullptr, ndir == 2 ? whh_t1 : whh_t0, nullptr, nullptr};
+  const size_t lds = (size_t)(LS_BC * 3 * H + LS_JB * LS_BC) * sizeof(float);
+  RVIT_CHECK_ARG(lds <= 64 * 1024, "gru_step_bwd: H = %d too wide for the LDS gate buffer", H);
+  hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / LS_JB, ndir), dim3(256), lds, st, dout, d0, d1, saved, out, dG, dhd,
+                     B, T, H, s, ndir);
+  RVIT_CHECK_LAUNCH("gru_step_bwd");
   return RVIT_OK;
 }

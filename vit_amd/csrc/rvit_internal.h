@@ -80,6 +80,11 @@ int rvit_lstm_step_fwd_impl(const float* x, const float* const* w, float* out, f
 int rvit_lstm_step_bwd_impl(const float* dout, const float* whh_t0, const float* whh_t1, const float* gates,
                             const float* cseq, float* dG, float* dc, int B, int T, int H, int s, int ndir,
                             hipStream_t st);
+int rvit_gru_step_fwd_impl(const float* x, const float* const* w, float* out, float* saved, int B, int T, int In, int H,
+                           int s, int ndir, hipStream_t st);
+int rvit_gru_step_bwd_impl(const float* dout, const float* whh_t0, const float* whh_t1, const float* saved,
+                           const float* out, float* dG, float* dhd, int B, int T, int H, int s, int ndir,
+                           hipStream_t st);
 int rvit_cast_bf16_impl(const float* x, bf16* out, long n, hipStream_t st);
 int rvit_transpose_batched_impl(const bf16* src, bf16* dst, const long* table, int n_entries, long total_tiles,
                                 hipStream_t st);

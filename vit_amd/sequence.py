@@ -6,11 +6,11 @@ The modules only HOLD parameters, under the reference's state_dict names (`spati
 `temporal_encoder.rnn.weight_ih_l0[_reverse]` ..., `classifier.0/.3.*`), so a `cnn_vit_lstm_radar.pt` checkpoint
 loads unchanged.  Arithmetic:
   * frames -> features: `CNNViTHybrid.forward_features` (engine / training engine of this package);
-  * LSTM: one fused HIP launch per time step for both directions (csrc/lstm.hip, fp32 straight from the fp32
+  * LSTM / GRU: one fused HIP launch per time step for both directions (csrc/lstm.hip, fp32 straight from the fp32
     parameters), the step's backward likewise; weight / bias / input gradients from the saved gate gradients
     with the package's GEMM kernels;
   * classifier: the same fused GEMM epilogues as the single-frame head.
-Only `model_type='lstm'` is built (the reference default, train_vit.py:267); 'gru' raises.
+Both `model_type='lstm'` (the reference default, train_vit.py:267) and 'gru' are built.
 There is no CPU path.
 """
 from __future__ import annotations
@@ -35,18 +35,21 @@ _M64 = (1 << 64) - 1
 
 
 class _LSTMParams(nn.Module):
-    """Parameter holder with nn.LSTM's names, shapes and default init (uniform +-1/sqrt(hidden))."""
+    """Parameter holder with nn.LSTM's / nn.GRU's names, shapes and default init (uniform +-1/sqrt(hidden));
+    `gates` = 4 (LSTM: i,f,g,o) or 3 (GRU: r,z,n)."""
 
-    def __init__(self, input_dim: int, hidden: int, num_layers: int, bidirectional: bool):
+    def __init__(self, input_dim: int, hidden: int, num_layers: int, bidirectional: bool, gates: int = 4):
         super().__init__()
         self.input_size, self.hidden_size, self.num_layers, self.bidirectional = input_dim, hidden, num_layers, bidirectional
+        self.gates = gates
         k = 1.0 / math.sqrt(hidden)
         ndir = 2 if bidirectional else 1
         for layer in range(num_layers):
             fin = input_dim if layer == 0 else hidden * ndir
             for sfx in ("", "_reverse")[:ndir]:
-                for name, shape in ((f"weight_ih_l{layer}{sfx}", (4 * hidden, fin)), (f"weight_hh_l{layer}{sfx}", (4 * hidden, hidden)),
-                                    (f"bias_ih_l{layer}{sfx}", (4 * hidden,)), (f"bias_hh_l{layer}{sfx}", (4 * hidden,))):
+                for name, shape in ((f"weight_ih_l{layer}{sfx}", (gates * hidden, fin)),
+                                    (f"weight_hh_l{layer}{sfx}", (gates * hidden, hidden)),
+                                    (f"bias_ih_l{layer}{sfx}", (gates * hidden,)), (f"bias_hh_l{layer}{sfx}", (gates * hidden,))):
                     self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
 
     def direction(self, layer: int, rev: bool):
@@ -59,16 +62,14 @@ class TemporalEncoder(nn.Module):
 
     def __init__(self, input_dim, hidden_dim=256, num_layers=2, dropout=0.3, bidirectional=True, model_type="lstm"):
         super().__init__()
-        if model_type == "gru":
-            raise NotImplementedError("TemporalEncoder: only model_type='lstm' has HIP kernels (the reference default)")
-        if model_type != "lstm":
+        if model_type not in ("lstm", "gru"):
             raise ValueError(f"Unknown model_type: {model_type}")
         if hidden_dim % 8 or input_dim % 4:
-            raise NotImplementedError("lstm kernels need hidden_dim % 8 == 0 and input_dim % 4 == 0")
+            raise NotImplementedError("the recurrent kernels need hidden_dim % 8 == 0 and input_dim % 4 == 0")
         self.model_type, self.bidirectional, self.hidden_dim = model_type, bidirectional, hidden_dim
         self.num_layers = num_layers
         self.dropout = float(dropout) if num_layers > 1 else 0.0
-        self.rnn = _LSTMParams(input_dim, hidden_dim, num_layers, bidirectional)
+        self.rnn = _LSTMParams(input_dim, hidden_dim, num_layers, bidirectional, gates=4 if model_type == "lstm" else 3)
         self.output_dim = hidden_dim * (2 if bidirectional else 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -92,15 +93,21 @@ def _lstm_forward(enc: TemporalEncoder, x: torch.Tensor, train: bool, base_seed:
     for layer in range(enc.num_layers):
         In = cur.shape[2]
         out = torch.empty(B, T, ndir * H, dtype=F32, device=x.device)
-        c = torch.empty(ndir, B, H, dtype=F32, device=x.device)
-        gates = torch.empty(B, T, ndir, 4 * H, dtype=F32, device=x.device) if train else None
-        cseq = torch.empty(B, T, ndir, H, dtype=F32, device=x.device) if train else None
+        lstm = enc.model_type == "lstm"
+        c = torch.empty(ndir, B, H, dtype=F32, device=x.device) if lstm else None
+        gates = torch.empty(B, T, ndir, 4 * H, dtype=F32, device=x.device) if train else None   # GRU: (r, z, n, hn)
+        cseq = torch.empty(B, T, ndir, H, dtype=F32, device=x.device) if train and lstm else None
         wf = [p.detach() for p in enc.rnn.direction(layer, False)]
         wr = [p.detach() for p in enc.rnn.direction(layer, True)] if ndir == 2 else [None] * 4
-        with ops._Span("lstm_fwd", 2 * B * T * ndir * 4 * H * (In + H), 0):
+        with ops._Span("rnn_fwd", 2 * B * T * ndir * enc.rnn.gates * H * (In + H), 0):
             for s in range(T):
-                check(lib.rvit_lstm_step_fwd(_ptr(cur), *[_ptr(w) for w in wf], *[_ptr(w) for w in wr], _ptr(out), _ptr(c),
-                                             _ptr(gates), _ptr(cseq), B, T, In, H, s, _stream()), "rvit_lstm_step_fwd")
+                if lstm:
+                    check(lib.rvit_lstm_step_fwd(_ptr(cur), *[_ptr(w) for w in wf], *[_ptr(w) for w in wr], _ptr(out),
+                                                 _ptr(c), _ptr(gates), _ptr(cseq), B, T, In, H, s, _stream()),
+                          "rvit_lstm_step_fwd")
+                else:
+                    check(lib.rvit_gru_step_fwd(_ptr(cur), *[_ptr(w) for w in wf], *[_ptr(w) for w in wr], _ptr(out),
+                                                _ptr(gates), B, T, In, H, s, _stream()), "rvit_gru_step_fwd")
         nxt = out
         seed = 0
         if train and enc.dropout > 0 and layer < enc.num_layers - 1:   # nn.LSTM: dropout on every layer's output but the last
@@ -123,35 +130,50 @@ def _lstm_backward(enc: TemporalEncoder, saved, dtop: torch.Tensor) -> Tuple[tor
         x, out = sv["x"], sv["out"]
         B, T, In = x.shape
         dev = x.device
-        dG = torch.empty(B, T, ndir, 4 * H, dtype=F32, device=dev)
-        dc = torch.empty(ndir, B, H, dtype=F32, device=dev)
+        lstm = enc.model_type == "lstm"
+        G = enc.rnn.gates * H                         # gate rows: 4H (LSTM) or 3H (GRU)
+        # LSTM: one set of pre-activation gradients; GRU: input-side then hidden-side (they differ in the n gate)
+        dG = torch.empty(B, T, ndir, G if lstm else 2 * G, dtype=F32, device=dev)
+        carry = torch.empty(ndir, B, H, dtype=F32, device=dev)
         whh_t = [enc.rnn.direction(layer, d == 1)[1].detach().t().contiguous() for d in range(ndir)]
-        with ops._Span("lstm_bwd", 2 * B * T * ndir * 4 * H * H, 0):
+        with ops._Span("rnn_bwd", 2 * B * T * ndir * G * H, 0):
             for s in reversed(range(T)):
-                check(lib.rvit_lstm_step_bwd(_ptr(dout), _ptr(whh_t[0]), _ptr(whh_t[1]) if ndir == 2 else None,
-                                             _ptr(sv["gates"]), _ptr(sv["cseq"]), _ptr(dG), _ptr(dc), B, T, H, s, _stream()),
-                      "rvit_lstm_step_bwd")
+                if lstm:
+                    check(lib.rvit_lstm_step_bwd(_ptr(dout), _ptr(whh_t[0]), _ptr(whh_t[1]) if ndir == 2 else None,
+                                                 _ptr(sv["gates"]), _ptr(sv["cseq"]), _ptr(dG), _ptr(carry), B, T, H, s,
+                                                 _stream()), "rvit_lstm_step_bwd")
+                else:
+                    check(lib.rvit_gru_step_bwd(_ptr(dout), _ptr(whh_t[0]), _ptr(whh_t[1]) if ndir == 2 else None,
+                                                _ptr(sv["gates"]), _ptr(out), _ptr(dG), _ptr(carry), B, T, H, s,
+                                                _stream()), "rvit_gru_step_bwd")
         x16 = x.reshape(B * T, In).to(BF16)
         dx = torch.empty(B * T, In, dtype=F32, device=dev)
         for d in range(ndir):
             sfx = "_reverse" if d else ""
             w_ih = enc.rnn.direction(layer, d == 1)[0].detach()
-            dGd = dG[:, :, d, :].reshape(B * T, 4 * H)                    # fp32, contiguous copy of this direction
+            dGd = dG[:, :, d, :G].reshape(B * T, G)                       # fp32, contiguous copy of this direction
+            dGh = dGd if lstm else dG[:, :, d, G:].reshape(B * T, G)      # hidden-side gradients (GRU)
             dG16 = dGd.to(BF16)
+            dGh16 = dG16 if lstm else dGh.to(BF16)
             hprev = torch.zeros(B, T, H, dtype=BF16, device=dev)          # h of the previous step of this direction
             if T > 1:
                 if d == 0:
                     hprev[:, 1:] = out[:, :-1, :H]
                 else:
                     hprev[:, :-1] = out[:, 1:, H:]
-            g_ih = torch.zeros(4 * H, In, dtype=F32, device=dev)
-            g_hh = torch.zeros(4 * H, H, dtype=F32, device=dev)
-            g_b = torch.zeros(4 * H, dtype=F32, device=dev)
+            g_ih = torch.zeros(G, In, dtype=F32, device=dev)
+            g_hh = torch.zeros(G, H, dtype=F32, device=dev)
+            g_b = torch.zeros(G, dtype=F32, device=dev)
             ops.wgrad(dG16, x16, g_ih)
-            ops.wgrad(dG16, hprev.view(B * T, H), g_hh)
+            ops.wgrad(dGh16, hprev.view(B * T, H), g_hh)
             ops.batch_sum(dGd, g_b)
+            if lstm:
+                g_bh = g_b.clone()
+            else:
+                g_bh = torch.zeros(G, dtype=F32, device=dev)
+                ops.batch_sum(dGh, g_bh)
             grads[f"weight_ih_l{layer}{sfx}"], grads[f"weight_hh_l{layer}{sfx}"] = g_ih, g_hh
-            grads[f"bias_ih_l{layer}{sfx}"], grads[f"bias_hh_l{layer}{sfx}"] = g_b, g_b.clone()
+            grads[f"bias_ih_l{layer}{sfx}"], grads[f"bias_hh_l{layer}{sfx}"] = g_b, g_bh
             # dx (+)= dG_d @ W_ih: gemm computes a @ w.T with w [N=In, K=4H]
             ops.gemm(dG16, w_ih.t().contiguous().to(BF16), dx, residual=dx if d else None)
         dx = dx.view(B, T, In)
