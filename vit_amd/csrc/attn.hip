@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-        if (key >= S) sc[kb][r] = -INFINITY;
+        if (kb == NKB - 1) {  // only the last key block can hold padding (the launcher picks NKB = ceil(S / 32))
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if (key >= S) sc[kb][r] = -INFINITY;
+        }
         mx = fmaxf(mx, sc[kb][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pe = exp2f((sc[kb][r] - mx) * scale_log2e);
+        const float pe = __builtin_amdgcn_exp2f((sc[kb][r] - mx) * scale_log2e);  // raw v_exp_f32: argument <= 0, flush-to-zero tail is fine
         sc[kb][r] = pe;
         sum += pe;
       }
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float pe = exp2f(sa[r] * c_l2 - lv[e] * 1.44269504088896340736f);
+          const float pe = __builtin_amdgcn_exp2f(sa[r] * c_l2 - lv[e] * 1.44269504088896340736f);
           float mult = 1.f;
           if (dk.thresh) {
             const int query = qb * 32 + 8 * g + 4 * h2 + e;
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-        const float pe = key < S ? exp2f(st[r] * c_l2 - lse_q) : 0.f;
+        const float pe = key < S ? __builtin_amdgcn_exp2f(st[r] * c_l2 - lse_q) : 0.f;
         float mult = 1.f;
         if (dk.thresh) mult = drop_mult(dk, (uint32_t)(((long)pair * S + qb * 32 + r32) * S + key));
         dpt[r] = pe * (dpt[r] * mult - del_q) * scale;
