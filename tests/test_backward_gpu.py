@@ -94,6 +94,42 @@ def test_conv_wgrad_and_dgrad(dev, cin, cout, hw, k, stride, pad):
     _close(dx, xr.grad.permute(0, 2, 3, 1) + res.float(), 1.0 / 128, 2e-2, "conv dgrad")
 
 
+@pytest.mark.parametrize("cin,cout,hw,B", [(64, 64, 56, 2), (128, 128, 28, 3), (256, 256, 14, 5), (512, 512, 7, 11),
+                                            (64, 128, 14, 1), (128, 64, 7, 40), (192, 64, 28, 2), (64, 64, 12, 3)])
+def test_conv3x3_wgrad_direct(dev, cin, cout, hw, B):
+    """The LDS-resident-patch weight-gradient kernel (csrc/wgrad3x3.hip, splits=-2) against torch autograd and against
+    the implicit-GEMM kernel (splits=-1): row-aligned tiles (56), tiles straddling image rows and images (28, 14, 7,
+    12), short last tiles, accumulation into a non-zero dW."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + hw + B)
+    x = _bf(torch.randn(B, hw, hw, cin, generator=g))
+    dy = _bf(torch.randn(B, hw, hw, cout, generator=g))
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), wr, None, 1, 1).backward(dy.float().permute(0, 3, 1, 2))
+    want = wr.grad.permute(0, 2, 3, 1)
+    init = torch.randn(cout, 9 * cin, generator=g)
+    dw = init.clone().to(dev)
+    ops.conv2d_wgrad(dy.to(dev), x.to(dev), dw, kh=3, kw=3, stride=1, pad=1, splits=-2)
+    _close((dw.cpu() - init).reshape(cout, 3, 3, cin), want, 2e-3 * math.sqrt(B * hw * hw / 6272), 2e-2, "direct conv wgrad")
+    dw2 = torch.zeros(cout, 9 * cin, device=dev)
+    ops.conv2d_wgrad(dy.to(dev), x.to(dev), dw2, kh=3, kw=3, stride=1, pad=1, splits=-1)
+    dw3 = torch.zeros(cout, 9 * cin, device=dev)
+    ops.conv2d_wgrad(dy.to(dev), x.to(dev), dw3, kh=3, kw=3, stride=1, pad=1)          # automatic: the direct kernel
+    # same bf16 products, fp32 sums in a different order
+    scale = dw2.abs().max().item()
+    assert (dw3 - dw2).abs().max().item() <= 1e-4 * scale + 1e-5
+
+
+def test_conv3x3_wgrad_direct_rejects_other_geometry(dev):
+    from vit_amd import ops
+    from vit_amd._lib import RvitError
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16, device=dev)
+    dy = torch.zeros(1, 4, 4, 64, dtype=torch.bfloat16, device=dev)
+    dw = torch.zeros(64, 9 * 64, device=dev)
+    with pytest.raises(RvitError):
+        ops.conv2d_wgrad(dy, x, dw, kh=3, kw=3, stride=2, pad=1, splits=-2)
+
+
 def test_conv1_wgrad_px4(dev):
     from vit_amd import ops
     B, H = 2, 224

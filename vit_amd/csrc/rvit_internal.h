@@ -106,10 +106,12 @@ struct WgradArgs {
   int N, N_store, K;
   int mode;        // 0 plain, 1 gather
   int H, W, Cpix, Ho, Wo, KW, stride, pad, seg_len;
-  int splits;      // 0 = auto
+  int splits;      // 0 = auto; > 0 M splits of the implicit-GEMM kernel; -1 force that kernel; -2 force the direct 3x3 kernel
 };
 
 int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st);
+bool rvit_conv3x3_wgrad_direct_ok(const WgradArgs& a);            // wgrad3x3.hip
+int rvit_conv3x3_wgrad_direct(const WgradArgs& a, hipStream_t st);
 
 int rvit_layernorm_fwd_impl(const void* x, int x_f32, long ldx, const float* gamma, const float* beta, void* y,
                             int y_f32, long ldy, float* mean, float* rstd, long rows, int E, float eps,

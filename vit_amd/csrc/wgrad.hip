@@ -230,6 +230,13 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
     RVIT_CHECK_ARG(a.M < 0x7fffffffL && a.Ho * a.Wo < 32768 * 4 && a.Wo < 32768, "wgrad: gather index range");
   }
   if (a.M == 0) return RVIT_OK;
+  // 3x3 / stride 1 convs: LDS-resident patch kernel (wgrad3x3.hip).  splits: 0 = automatic choice, -2 forces it,
+  // -1 or an explicit split count keep the implicit-GEMM kernel below (tests compare the two)
+  if (a.splits == -2 || (a.splits == 0 && rvit_conv3x3_wgrad_direct_ok(a))) {
+    WgradArgs d = a;
+    d.splits = 0;
+    return rvit_conv3x3_wgrad_direct(d, st);
+  }
   const long tiles = (long)((a.N + 127) / 128) * ((a.K + 127) / 128);
   const long mtiles = (a.M + TM - 1) / TM;
   // ~1024 workgroups (two fit a CU at 64 KB LDS each; two rounds measured best on the stem shapes,
