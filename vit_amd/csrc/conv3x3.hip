@@ -35,6 +35,17 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_base)
   __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Exact floor division by a runtime divisor through its float reciprocal + one fix-up (0 <= m < 2^31, quotient
+// error of the float product < 1 for the ranges the host admits): ~8 VALU instructions instead of the ~40 of the
+// integer division sequence.  The per-workgroup set-up below does ~30 of them per thread; with `/` that set-up cost
+// more vector-ALU time than the 9-tap MFMA loop of a 64-channel layer.
+__device__ __forceinline__ int c3_fdiv(int m, int d, float inv_d) {
+  int q = (int)((float)m * inv_d);
+  const int r = m - q * d;
+  if (r < 0) --q;
+  if (r >= d) ++q;
+  return q;
+}
 
 constexpr int C3_BM = 256;
 constexpr int C3_PMAX = 640;  // patch pixels a workgroup can stage (DMA pass budget)
@@ -137,17 +148,18 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
   // padded-row window of this tile
   long m_last = m0 + tile_len - 1;
   if (m_last >= p.M) m_last = p.M - 1;
+  const float inv_hw = 1.0f / (float)hw, inv_w = 1.0f / (float)W, inv_pw = 1.0f / (float)PW, inv_hp = 1.0f / (float)HP;
   int R_first, R_last;
   {
-    const int b0 = (int)(m0 / hw), r0 = (int)(m0 - (long)b0 * hw);
-    const int b1 = (int)(m_last / hw), r1 = (int)(m_last - (long)b1 * hw);
-    R_first = b0 * HP + r0 / W + 1;
-    R_last = b1 * HP + r1 / W + 1;
+    const int b0 = c3_fdiv((int)m0, hw, inv_hw), r0 = (int)m0 - b0 * hw;
+    const int b1 = c3_fdiv((int)m_last, hw, inv_hw), r1 = (int)m_last - b1 * hw;
+    R_first = b0 * HP + c3_fdiv(r0, W, inv_w) + 1;
+    R_last = b1 * HP + c3_fdiv(r1, W, inv_w) + 1;
   }
   const int R0 = R_first - 1;                       // first padded row held by the patch
   const int P = (R_last - R_first + 3) * PW;        // patch pixels (host guarantees P*128 <= patch_bytes)
   const int npass = (P + 7) >> 3;                   // 8 pixels (1 KB) per wave-level DMA instruction
-  const int nB = (int)(p.M / hw);                   // images
+  const int nB = c3_fdiv((int)p.M, hw, inv_hw);     // images
 
   // ---- per-thread patch DMA descriptors: pixel offset (in pixels) or -1 for zero fill ----------
   const int prow_l = lane >> 3;
@@ -161,9 +173,9 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
     const int row = pass * 8 + prow_l;              // LDS row = patch pixel index
     pix[it] = -1;
     if (pass < npass && row < P) {
-      const int pr = row / PW, pc = row - pr * PW;
+      const int pr = c3_fdiv(row, PW, inv_pw), pc = row - pr * PW;
       const int Rp = R0 + pr;
-      const int b = Rp / HP, hh = Rp - b * HP - 1, ww = pc - 1;
+      const int b = c3_fdiv(Rp, HP, inv_hp), hh = Rp - b * HP - 1, ww = pc - 1;
       if (b < nB && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) pix[it] = (b * H + hh) * W + ww;
     }
   }
@@ -182,8 +194,8 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
   for (int i = 0; i < MR; ++i) {
     long m = m0 + wm * WM + i * 16 + fr;
     if (m > m_last) m = m0;  // any in-window pixel: the result is discarded by the epilogue
-    const int b = (int)(m / hw), r = (int)(m - (long)b * hw);
-    const int h = r / W, w = r - h * W;
+    const int b = c3_fdiv((int)m, hw, inv_hw), r = (int)m - b * hw;
+    const int h = c3_fdiv(r, W, inv_w), w = r - h * W;
     pb[i] = (b * HP + h + 1 - R_first) * PW + w;
   }
   const int sw_b = (fr >> 1) & 7;
@@ -315,7 +327,9 @@ bool rvit_conv3x3_direct_ok(const GemmArgs& a) {
   if (a.act == RVIT_ACT_GELU || (a.R && a.ldr != a.N) || a.ldc != a.N || a.ldb != a.K) return false;
   const int P = c3_patch_pixels(a.H, a.W);
   if (P > C3_PMAX) return false;                        // DMA pass budget
-  if (a.M % ((long)a.H * a.W) != 0) return false;
+  if (a.M % ((long)a.H * a.W) != 0 || a.M >= 0x7fffffffL) return false;
+  // index ranges of the kernel: padded rows in 31 bits, quotients of the float-reciprocal divisions below 2^22
+  if ((long)a.M / ((long)a.H * a.W) >= (1L << 22)) return false;
   return (long)a.M / ((long)a.H * a.W) * (a.H + 2) < 0x7fffffffL / (a.W + 2);
 }
 

@@ -84,11 +84,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
     const long grow = bm0 + lrow + RPP * i;
     const bool ok = grow < p.M;
     if constexpr (GATHER) {
-      const long g = ok ? grow : 0;
+      // float-reciprocal floor division + fix-up (exact for the ranges the dispatcher admits): the 64-bit `/`
+      // sequence cost ~150 vector-ALU instructions per row, four rows per thread, before the first MFMA
+      const int g = ok ? (int)grow : 0;
       const int hw = p.Ho * p.Wo;
-      const int b = (int)(g / hw);
-      const int rem = (int)(g - (long)b * hw);
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      int b = (int)((float)g * (1.0f / (float)hw));
+      int rem = g - b * hw;
+      if (rem < 0) { --b; rem += hw; }
+      if (rem >= hw) { ++b; rem -= hw; }
+      int ho = (int)((float)rem * (1.0f / (float)p.Wo));
+      int wo = rem - ho * p.Wo;
+      if (wo < 0) { --ho; wo += p.Wo; }
+      if (wo >= p.Wo) { ++ho; wo -= p.Wo; }
       int hi0, wi0;
       if (p.transposed) {  // rows are pixels of dX; taps walk dY at (ho + pad - kh) / stride
         hi0 = ok ? ho + p.pad : -20000;
@@ -390,6 +397,8 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     RVIT_CHECK_ARG((a.Cpix & 3) == 0 && (a.seg_len & 7) == 0 && a.seg_len > 0 && a.KW > 0,
                    "conv: bad gather geometry Cpix=%d seg_len=%d KW=%d", a.Cpix, a.seg_len, a.KW);
     RVIT_CHECK_ARG(a.H < 20000 && a.W < 20000, "conv: image too large for packed coordinates");
+    RVIT_CHECK_ARG(a.Ho > 0 && a.Wo > 0 && a.M < 0x7fffffffL && a.M / ((long)a.Ho * a.Wo) < (1L << 22),
+                   "conv: M=%ld outside the kernel's 32-bit row decomposition", a.M);
     RVIT_CHECK_ARG(!a.transposed || a.stride == 1 || a.stride == 2, "conv dgrad: stride must be 1 or 2");
   }
   if (a.drop_mode) {
