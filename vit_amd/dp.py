@@ -65,8 +65,6 @@ class BucketReducer:
         """Elements [0, upto) of `flat` are final; launch a bucket if enough has accumulated."""
         if self.world <= 1:
             return
-        if self.done == 0 and not self.buckets:
-            pass
         if upto - self.done >= self.bucket_elems:
             self._launch(flat, self.done, upto)
 
