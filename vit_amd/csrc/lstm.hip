@@ -4,7 +4,7 @@
 //   pre = W_ih x_t + b_ih + W_hh h_prev + b_hh;  i,f,o = sigmoid, g = tanh;  c = f*c_prev + i*g;  h = o*tanh(c)
 // The recurrence is tiny next to the spatial encoder (5 MFLOP against 3.97 GFLOP per frame) and strictly
 // sequential, so it runs in fp32 on the vector ALUs straight from the fp32 parameters: no packing, no bf16
-// rounding inside the recurrence.  A workgroup owns LS_JB hidden units of one direction for every sample:
+// rounding inside the recurrence.  A workgroup owns LS_JB hidden units of one direction for LS_BC samples:
 // 256 threads = 32 gate rows x 8 K-parts (forward) or 8 units x 32 K-parts (backward); the step's input
 // vectors sit in LDS, the weight rows stream through registers once per chunk of 8 samples.
 #include "common.h"
@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const float* __restr
   const float* wi = w.w_ih + (long)row * In;
   const float* wh = w.w_hh + (long)row * H;
   const int OW = ndir * H;
-  for (int b0 = 0; b0 < B; b0 += LS_BC) {
+  {  // one chunk of LS_BC samples per workgroup: blockIdx.z (samples are independent)
+    const int b0 = blockIdx.z * LS_BC;
     const int nb = B - b0 < LS_BC ? B - b0 : LS_BC;
     __syncthreads();   // previous chunk's cell update has read `pre`
     for (int i = threadIdx.x; i < LS_BC * K; i += 256) {
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const float* __restr
   const int jj = threadIdx.x >> 5, p = threadIdx.x & 31;
   const float* wr = whh_t + (long)(j0 + jj) * G4;
   const int OW = ndir * H;
-  for (int b0 = 0; b0 < B; b0 += LS_BC) {
+  {  // one chunk of LS_BC samples per workgroup: blockIdx.z (samples are independent)
+    const int b0 = blockIdx.z * LS_BC;
     const int nb = B - b0 < LS_BC ? B - b0 : LS_BC;
     __syncthreads();
     if (s < T - 1) {
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(256) void gru_step_fwd_kernel(const float* __restri
   const float* wh = w.w_hh + (long)grow * H;
   const int k_lo = q == 3 ? In : 0, k_hi = q == 2 ? In : K;
   const int OW = ndir * H;
-  for (int b0 = 0; b0 < B; b0 += LS_BC) {
+  {  // one chunk of LS_BC samples per workgroup: blockIdx.z (samples are independent)
+    const int b0 = blockIdx.z * LS_BC;
     const int nb = B - b0 < LS_BC ? B - b0 : LS_BC;
     __syncthreads();
     for (int i = threadIdx.x; i < LS_BC * K; i += 256) {
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
   const int jj = threadIdx.x >> 5, p = threadIdx.x & 31;
   const float* wr = whh_t + (long)(j0 + jj) * G3;
   const int OW = ndir * H;
-  for (int b0 = 0; b0 < B; b0 += LS_BC) {
+  {  // one chunk of LS_BC samples per workgroup: blockIdx.z (samples are independent)
+    const int b0 = blockIdx.z * LS_BC;
     const int nb = B - b0 < LS_BC ? B - b0 : LS_BC;
     __syncthreads();
     if (s < T - 1) {
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256) void gru_step_bwd_kernel(const float* __restri
 }  // namespace
 
 static int lstm_check(int B, int T, int In, int H, int s, int ndir) {
-  RVIT_CHECK_ARG(B > 0 && T > 0 && s >= 0 && s < T && (ndir == 1 || ndir == 2), "lstm: bad B=%d T=%d step=%d ndir=%d", B, T, s, ndir);
+  RVIT_CHECK_ARG(B > 0 && B <= 65535 * 8 && T > 0 && s >= 0 && s < T && (ndir == 1 || ndir == 2), "lstm: bad B=%d T=%d step=%d ndir=%d", B, T, s, ndir);
   RVIT_CHECK_ARG(H > 0 && H % LS_JB == 0 && (H & 3) == 0 && In > 0 && (In & 3) == 0, "lstm: H must be a multiple of 8 and In of 4 (H=%d In=%d)", H, In);
   return RVIT_OK;
 }
@@ -333,7 +337,7 @@ int rvit_lstm_step_fwd_impl(const float* x, const float* const* w, float* out, f
   const LstmDir d1 = ndir == 2 ? LstmDir{w[4], w[5], w[6], w[7]} : d0;
   const size_t lds = (size_t)(LS_BC * (In + H) + 32 * LS_BC) * sizeof(float);
   RVIT_CHECK_ARG(lds <= 64 * 1024, "lstm_step_fwd: In + H = %d too wide for the LDS vector buffer", In + H);
-  hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(H / LS_JB, ndir), dim3(256), lds, st, x, d0, d1, out, c, gates, cseq, B,
+  hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3(H / LS_JB, ndir, (B + LS_BC - 1) / LS_BC), dim3(256), lds, st, x, d0, d1, out, c, gates, cseq, B,
                      T, In, H, s, ndir);
   RVIT_CHECK_LAUNCH("lstm_step_fwd");
   return RVIT_OK;
@@ -348,7 +352,7 @@ int rvit_lstm_step_bwd_impl(const float* dout, const float* whh_t0, const float*
   const LstmDir d0{nullptr, whh_t0, nullptr, nullptr}, d1{nullptr, ndir == 2 ? whh_t1 : whh_t0, nullptr, nullptr};
   const size_t lds = (size_t)(LS_BC * 4 * H + LS_JB * LS_BC) * sizeof(float);
   RVIT_CHECK_ARG(lds <= 64 * 1024, "lstm_step_bwd: H = %d too wide for the LDS gate buffer", H);
-  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(H / LS_JB, ndir), dim3(256), lds, st, dout, d0, d1, gates, cseq, dG, dc,
+  hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3(H / LS_JB, ndir, (B + LS_BC - 1) / LS_BC), dim3(256), lds, st, dout, d0, d1, gates, cseq, dG, dc,
                      B, T, H, s, ndir);
   RVIT_CHECK_LAUNCH("lstm_step_bwd");
   return RVIT_OK;
@@ -364,7 +368,7 @@ int rvit_gru_step_fwd_impl(const float* x, const float* const* w, float* out, fl
   const LstmDir d1 = ndir == 2 ? LstmDir{w[4], w[5], w[6], w[7]} : d0;
   const size_t lds = (size_t)(LS_BC * (In + H) + 32 * LS_BC) * sizeof(float);
   RVIT_CHECK_ARG(lds <= 64 * 1024, "gru_step_fwd: In + H = %d too wide for the LDS vector buffer", In + H);
-  hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(H / LS_JB, ndir), dim3(256), lds, st, x, d0, d1, out, saved, B, T, In, H,
+  hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(H / LS_JB, ndir, (B + LS_BC - 1) / LS_BC), dim3(256), lds, st, x, d0, d1, out, saved, B, T, In, H,
                      s, ndir);
   RVIT_CHECK_LAUNCH("gru_step_fwd");
   return RVIT_OK;
@@ -379,7 +383,7 @@ int rvit_gru_step_bwd_impl(const float* dout, const float* whh_t0, const float* 
   const LstmDir d0{nullptr, whh_t0, nullptr, nullptr}, d1{nullptr, ndir == 2 ? whh_t1 : whh_t0, nullptr, nullptr};
   const size_t lds = (size_t)(LS_BC * 3 * H + LS_JB * LS_BC) * sizeof(float);
   RVIT_CHECK_ARG(lds <= 64 * 1024, "gru_step_bwd: H = %d too wide for the LDS gate buffer", H);
-  hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / LS_JB, ndir), dim3(256), lds, st, dout, d0, d1, saved, out, dG, dhd,
+  hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(H / LS_JB, ndir, (B + LS_BC - 1) / LS_BC), dim3(256), lds, st, dout, d0, d1, saved, out, dG, dhd,
                      B, T, H, s, ndir);
   RVIT_CHECK_LAUNCH("gru_step_bwd");
   return RVIT_OK;
