@@ -24,6 +24,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) owns a contiguous run of tiles.
 #include "common.h"
 #include "rvit_internal.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -253,104 +254,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
     const int row = pass * 8 + er;
     const long m = bm0 + wm * WM + row;
     if (m >= p.M || n >= p.N) continue;
-    long orow = m;
-    if (p.row_group > 0) {
-      const long g = m / p.row_group;
-      orow = g * (p.row_group + p.row_extra) + (m - g * p.row_group) + p.row_extra;
-    }
-    const long rrow = p.r_period > 0 ? (m % p.r_period) : orow;
     float v[8];
     {
       const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4);
       const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4 + 16);
       v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
     }
-    if (p.vec) {
-      if (p.scale) {
-        const float4 a = *reinterpret_cast<const float4*>(p.scale + n);
-        const float4 b = *reinterpret_cast<const float4*>(p.scale + n + 4);
-        v[0] *= a.x; v[1] *= a.y; v[2] *= a.z; v[3] *= a.w; v[4] *= b.x; v[5] *= b.y; v[6] *= b.z; v[7] *= b.w;
-      }
-      if (p.bias) {
-        const float4 a = *reinterpret_cast<const float4*>(p.bias + n);
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n + 4);
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-      }
-      if (p.gate) {
-        const uint4 gq = *reinterpret_cast<const uint4*>(p.G + orow * p.ldg + n);
-        const float gv[8] = {bf16_lo(gq.x), bf16_hi(gq.x), bf16_lo(gq.y), bf16_hi(gq.y),
-                             bf16_lo(gq.z), bf16_hi(gq.z), bf16_lo(gq.w), bf16_hi(gq.w)};
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          v[e] *= p.gate == RVIT_GATE_GELU_GRAD ? gelu_erf_grad(gv[e]) : (gv[e] > 0.f ? 1.f : 0.f);
-      }
-      if (p.C2) {
-        uint4 o;
-        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(p.C2 + orow * p.ldc2 + n) = o;
-      }
-      if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) {
-        const uint32_t di = (uint32_t)(orow * p.N + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
-      }
-      if (p.R) {
-        if (p.r_f32) {
-          const float* rp = (const float*)p.R + rrow * p.ldr + n;
-          const float4 a = *reinterpret_cast<const float4*>(rp);
-          const float4 b = *reinterpret_cast<const float4*>(rp + 4);
-          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-        } else {
-          const uint4 r = *reinterpret_cast<const uint4*>((const bf16*)p.R + rrow * p.ldr + n);
-          v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
-          v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
-        }
-      }
-      if (p.act == RVIT_ACT_RELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-      } else if (p.act == RVIT_ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-      }
-      if (p.drop_mode == RVIT_DROP_POST_ACT) {
-        const uint32_t di = (uint32_t)(orow * p.N + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
-      }
-      if (p.c_f32) {
-        float* cp = (float*)p.C + orow * p.ldc + n;
-        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-        uint4 o;
-        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-        *reinterpret_cast<uint4*>((bf16*)p.C + orow * p.ldc + n) = o;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (n + e >= p.N) break;
-        float x = v[e];
-        if (p.scale) x *= p.scale[n + e];
-        if (p.bias) x += p.bias[n + e];
-        if (p.gate) {
-          const float gv = (float)p.G[orow * p.ldg + n + e];
-          x *= p.gate == RVIT_GATE_GELU_GRAD ? gelu_erf_grad(gv) : (gv > 0.f ? 1.f : 0.f);
-        }
-        if (p.C2) p.C2[orow * p.ldc2 + n + e] = (bf16)x;
-        if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) x *= drop_mult(p.drop, (uint32_t)(orow * p.N + n + e));
-        if (p.R) x += p.r_f32 ? ((const float*)p.R)[rrow * p.ldr + n + e]
-                              : (float)((const bf16*)p.R)[rrow * p.ldr + n + e];
-        if (p.act == RVIT_ACT_RELU) x = fmaxf(x, 0.f);
-        else if (p.act == RVIT_ACT_GELU) x = gelu_erf(x);
-        if (p.drop_mode == RVIT_DROP_POST_ACT) x *= drop_mult(p.drop, (uint32_t)(orow * p.N + n + e));
-        if (p.c_f32) ((float*)p.C)[orow * p.ldc + n + e] = x;
-        else ((bf16*)p.C)[orow * p.ldc + n + e] = (bf16)x;
-      }
-    }
+    rvit_gemm_epilogue_row8(p, v, m, n);
   }
 }
 
