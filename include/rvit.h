@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 3
+#define RVIT_ABI_VERSION 4
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
