@@ -260,3 +260,12 @@ def test_fused_optimizer_requires_engine_gradients(dev):
         opt.step()
     with pytest.raises(RuntimeError):
         FusedAdamW(CNNViTHybrid(num_classes=11, embed_dim=128, num_heads=2, num_layers=1, backbone="patch16"))
+    # frozen parameters: torch optimisers skip them, the flat kernels cannot -> refused
+    from vit_amd.synth import micro_doppler_batch
+    m.train()
+    m(micro_doppler_batch(2, seed=1).to(dev)).sum().backward()
+    m.pos_embed.requires_grad = False
+    with pytest.raises(RuntimeError, match="frozen"):
+        opt.step()
+    m.pos_embed.requires_grad = True
+    opt.step()

@@ -65,6 +65,11 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("FusedAdamW: closures are not supported")
+        if not all(p.requires_grad for p in self.param_groups[0]["params"]):
+            # torch optimisers skip parameters without a gradient (freeze_backbone, train_vit.py:310-318); the flat
+            # kernels update every element, weight decay included, so refuse instead of silently unfreezing
+            raise RuntimeError("FusedAdamW: frozen parameters (requires_grad=False) are not supported; "
+                               "use a torch optimiser while part of the model is frozen")
         flat_g = getattr(self._eng, "last_flat", None)
         first = next(iter(self.model.parameters()))
         if flat_g is None or first.grad is None:
