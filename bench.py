@@ -275,6 +275,8 @@ def main():
     ap.add_argument("--stock-optimizer", action="store_true",
                     help="training legs: clip_grad_norm_ + torch.optim.AdamW(fused=True) instead of vit_amd.optim.FusedAdamW")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput leg")
+    ap.add_argument("--train-timeout", type=float, default=240.0,
+                    help="seconds after which a stalled training leg is abandoned (the inference line is still printed)")
     ap.add_argument("--workload", choices=["hybrid", "vitb-train", "vitl-infer-fp8"], default="hybrid",
                     help="hybrid = the headline (BASELINE configs[1] inference + configs[2] training leg); "
                          "vitb-train = BASELINE configs[3], ViT-B/16-scale training samples/s; "
@@ -393,23 +395,19 @@ def main():
                         "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": k["launches"] // min(args.steps, 5)}
 
     _say(rank, "inference: done")
-    train = None
-    if not args.no_train:
-        del x
-        train = train_leg(args, dev, dist, world, rank, sd)
-
-    if rank == 0 and roofline is not None:
-        roofline["algorithmic_bytes_per_launch"] = round(kernels[roofline["kernel"]]["bytes"] / kernels[roofline["kernel"]]["launches"])
-        # HBM traffic of the same kernel from the committed PMC passes (profiles/, same command and batch)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_pmc_r01.json")
-        if os.path.exists(pmc):
-            with open(pmc) as fh:
-                t = json.load(fh)
-            if t.get("kernel") == roofline["kernel"] and t.get("batch_per_gpu") == B:
-                roofline["traffic"] = t["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = ("bench_pmc_r01.json = profiles/r01_pmc_traffic.json (rocprofv3 --pmc "
-                                              "FETCH_SIZE x2 + WRITE_SIZE, per launch, same command)")
+    out = None
     if rank == 0:
+        if roofline is not None:
+            roofline["algorithmic_bytes_per_launch"] = round(kernels[roofline["kernel"]]["bytes"] / kernels[roofline["kernel"]]["launches"])
+            # HBM traffic of the same kernel from the committed PMC passes (profiles/, same command and batch)
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_pmc_r01.json")
+            if os.path.exists(pmc):
+                with open(pmc) as fh:
+                    t = json.load(fh)
+                if t.get("kernel") == roofline["kernel"] and t.get("batch_per_gpu") == B:
+                    roofline["traffic"] = t["traffic_bytes_per_launch"]
+                    roofline["traffic_source"] = ("bench_pmc_r01.json = profiles/r01_pmc_traffic.json (rocprofv3 --pmc "
+                                                  "FETCH_SIZE x2 + WRITE_SIZE, per launch, same command)")
         frames = world * B * args.steps
         value = frames / dt
         out = {
@@ -424,6 +422,27 @@ def main():
             "roofline": roofline,
             "kernel_ms_per_step": {n: round(v["ms"] / min(args.steps, 5), 4) for n, v in sorted(kernels.items())},
         }
+
+    train = None
+    if not args.no_train:
+        del x
+        # The headline above is already measured: a secondary leg that stalls (a wedged collective, a lost peer)
+        # must not take it down.  After --train-timeout seconds every rank gives up; rank 0 still prints the line.
+        import threading
+
+        def give_up():
+            if out is not None:
+                out["train"] = {"error": f"training leg did not finish within {args.train_timeout:.0f} s; skipped"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.train_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        train = train_leg(args, dev, dist, world, rank, sd)
+        dog.cancel()
+
+    if rank == 0:
         if train is not None:
             out["train"] = train
         if world == 1 and not args.no_cpu_baseline:
