@@ -308,6 +308,58 @@ def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant)
     _close(dx, want, 1.0 / 128, 2e-2, "direct dgrad")
 
 
+@pytest.mark.parametrize("B,H", [(1, 56), (3, 56), (2, 8), (37, 56), (300, 4)])
+@pytest.mark.parametrize("plain", [False, True])
+def test_conv3x3_weights_resident_variant(dev, B, H, plain):
+    """The 64 -> 64 channel kernel with the filter bank resident in LDS (tile 14, csrc/conv3x3_c64.hip; what
+    layer1 of the stem runs): against torch, and BIT-EXACT against the generic direct kernel (tile 11: same
+    products, same fp32 summation order), forward and flipped (input-gradient) form; fewer tiles than CUs, more
+    tiles than CUs (persistent loop, both patch buffers), single-tile images (H = 4: both halo rows zero)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(7 * B + H)
+    x = _bf(torch.randn(B, H, 56, 64, generator=g))
+    w = _bf(torch.randn(64, 3, 3, 64, generator=g) / 24.0)
+    kw = {}
+    ref = _conv_ref(x, w, 1, 1)
+    if not plain:
+        scale = torch.rand(64, generator=g) + 0.5
+        bias = torch.randn(64, generator=g)
+        res = _bf(torch.randn(B, H, 56, 64, generator=g))
+        ref = torch.relu(ref * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res.float().permute(0, 3, 1, 2))
+        kw = dict(scale=scale.to(dev), bias=bias.to(dev), residual=res.to(dev), act="relu")
+    out = torch.full((B, H, 56, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.conv2d(x.to(dev), w.reshape(64, -1).to(dev), out, kh=3, kw=3, stride=1, pad=1, tile=14, **kw)
+    _close(out, ref.permute(0, 2, 3, 1), 1.0 / 128, 3e-3, "weights-resident conv")
+    out1 = torch.empty_like(out)
+    ops.conv2d(x.to(dev), w.reshape(64, -1).to(dev), out1, kh=3, kw=3, stride=1, pad=1, tile=11, **kw)
+    assert torch.equal(out, out1)
+    auto = torch.empty_like(out)
+    ops.conv2d(x.to(dev), w.reshape(64, -1).to(dev), auto, kh=3, kw=3, stride=1, pad=1, **kw)
+    assert torch.equal(out, auto)
+    dy = _bf(torch.randn(B, H, 56, 64, generator=g))
+    w_t = w.permute(3, 1, 2, 0).reshape(64, 9 * 64).contiguous()
+    resx = None if plain else _bf(torch.randn(B, H, 56, 64, generator=g)).to(dev)
+    dx = torch.full((B, H, 56, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    dx1 = torch.empty_like(dx)
+    ops.conv2d_dgrad(dy.to(dev), w_t.to(dev), dx, kh=3, kw=3, stride=1, pad=1, tile=14, residual=resx)
+    ops.conv2d_dgrad(dy.to(dev), w_t.to(dev), dx1, kh=3, kw=3, stride=1, pad=1, tile=11, residual=resx)
+    assert torch.equal(dx, dx1)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    F.conv2d(xr, w.float().permute(0, 3, 1, 2), None, 1, 1).backward(dy.float().permute(0, 3, 1, 2))
+    want = xr.grad.permute(0, 2, 3, 1) + (0 if plain else resx.float().cpu())
+    _close(dx, want, 1.0 / 128, 2e-2, "weights-resident dgrad")
+
+
+def test_conv3x3_weights_resident_rejects_other_geometry(dev):
+    from vit_amd import ops
+    from vit_amd._lib import RvitError
+    x = torch.zeros(1, 28, 28, 128, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(128, 9 * 128, dtype=torch.bfloat16, device=dev)
+    y = torch.zeros(1, 28, 28, 128, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RvitError):
+        ops.conv2d(x, w, y, kh=3, kw=3, stride=1, pad=1, tile=14)
+
+
 def test_conv3x3_direct_rejects_other_geometry(dev):
     from vit_amd import ops
     from vit_amd._lib import RvitError

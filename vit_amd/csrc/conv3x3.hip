@@ -356,8 +356,14 @@ static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream
 }
 
 // variant: 0 = automatic, 1 = BN 64 (single patch buffer), 2 = BN 128 with two patch buffers, 3 = BN 64 with
-// 4 waves of 64 x 64
+// 4 waves of 64 x 64, 4 = the weights-resident 64 -> 64 channel kernel (conv3x3_c64.hip; automatic where it applies:
+// a property of the layer geometry, never of the batch size)
 int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
+  if (variant == 4) {
+    RVIT_CHECK_ARG(rvit_conv3x3_c64_ok(a), "conv3x3: the weights-resident variant needs 64 -> 64 channels on 56-wide maps");
+    return rvit_conv3x3_c64(a, st);
+  }
+  if (variant == 0 && rvit_conv3x3_c64_ok(a)) return rvit_conv3x3_c64(a, st);
   const int P = c3_patch_pixels(a.H, a.W);
   const int patch_bytes = ((P + 7) / 8) * 1024;
   const int tr = c3_tile_rows(a.H, a.W);

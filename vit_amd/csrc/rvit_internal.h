@@ -44,6 +44,8 @@ struct GemmArgs {
 int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream);
 bool rvit_conv3x3_direct_ok(const GemmArgs& a);               // conv3x3.hip
 int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t stream);
+bool rvit_conv3x3_c64_ok(const GemmArgs& a);                  // conv3x3_c64.hip (64 -> 64 channels, weights resident)
+int rvit_conv3x3_c64(const GemmArgs& a, hipStream_t stream);
 int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
                               int B, int relu, hipStream_t st);  // conv1.hip
 

@@ -245,7 +245,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
     # the 3x3 / stride 1 / pad 1 convs run the LDS-resident-patch kernel (csrc/conv3x3.hip), everything else
     # the implicit-GEMM gather kernel (csrc/gemm.hip): profile them under separate names
     direct = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and seg_len is None and Cpix % 64 == 0
-              and Cout % 64 == 0 and (tile == 0 or 10 <= tile <= 13))
+              and Cout % 64 == 0 and (tile == 0 or 10 <= tile <= 14))
     with _Span("conv3x3_direct" if direct else "conv2d_gather", 2 * B * Ho * Wo * Cout * true_k,
                _nbytes(x, w, out, residual)):
         check(lib.rvit_conv2d_fwd_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cpix, seg, kh, kw, stride,
