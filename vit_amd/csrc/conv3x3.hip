@@ -15,8 +15,11 @@
 // the image.  The patch holds padded rows R_first-1 .. R_last+1, all W+2 columns, 128 B (64 bf16)
 // per pixel; a pixel outside the image is DMA'd from a 16-byte zero page.  LDS row index of the
 // fragment row of output m for tap (kh,kw):  pb(m) + kh*(W+2) + kw,  pb = (R - R_first)*(W+2) + w.
-// The 16-byte chunk index inside a row is XOR-swizzled with (row>>1)&7 on the DMA source and on the
-// ds_read_b128 (same involution as gemm.hip): 16 consecutive rows read conflict-free.
+// The 16-byte chunk index inside a patch row is XOR-swizzled with row & 6 on the DMA source and on the
+// ds_read_b128: a 16-lane group of that read pairs rows {0-3,12-15} at chunk c with rows {4-11} at chunk c^1, so
+// with chunk bit 0 left alone and bits [2:1] XORed by row bits [2:1] ANY 16 consecutive rows are conflict-free,
+// whatever the alignment of the first (tap offsets make it arbitrary); gemm.hip's (row>>1)&7 needs row % 4 == 0
+// and stays in use for the weight tile, whose rows are aligned.
 //
 // Structure: 8 waves, v_mfma_f32_16x16x32_bf16 with the weights on the A side, two variants (below);
 // epilogue identical to gemm.hip's (accumulators restaged through LDS, whole 128-byte row
@@ -164,9 +167,8 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
   // ---- per-thread patch DMA descriptors: pixel offset (in pixels) or -1 for zero fill ----------
   const int prow_l = lane >> 3;
   int pix[C3_PIT];
-  // source chunk = slot ^ ((row>>1)&7); row = pass*8 + prow_l and pass = wave + 8*it, so the swizzle term
-  // ((pass&1)*4 + (prow_l>>1)) & 7 is the same for every pass of this thread
-  const int pchunk = ((lane & 7) ^ ((((wave & 1) << 2) + (prow_l >> 1)) & 7)) * 8;
+  // source chunk = slot ^ (row & 6); row = pass*8 + prow_l, so the swizzle term is prow_l & 6 for every pass
+  const int pchunk = ((lane & 7) ^ (prow_l & 6)) * 8;
 #pragma unroll
   for (int it = 0; it < C3_PIT; ++it) {
     const int pass = wave + it * C3_WAVES;
@@ -246,7 +248,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
           for (int i = 0; i < MR; ++i) { \
             const int row = pb[i] + roff; \
-            af[i] = *reinterpret_cast<const bf16x8*>(patch + row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4)); \
+            af[i] = *reinterpret_cast<const bf16x8*>(patch + row * 128 + (((ks * 4 + fq) ^ (row & 6)) << 4)); \
           } \
 _Pragma("unroll") \
           for (int j = 0; j < 4; ++j) \
