@@ -25,8 +25,8 @@ def bench(fn, iters=30):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     dev = torch.device("cuda:0")
-    for name, c, hw, tiles in (("layer1", 64, 56, (11, 14)), ("layer2", 128, 28, (11,)), ("layer3", 256, 14, (11,)),
-                               ("layer4", 512, 7, (11,))):
+    for name, c, hw, tiles in (("layer1", 64, 56, (11, 14)), ("layer2", 128, 28, (11, 12, 13)), ("layer3", 256, 14, (11, 12, 13)),
+                               ("layer4", 512, 7, (11, 12, 13))):
         x = torch.randn(B, hw, hw, c, device=dev).bfloat16()
         w = (torch.randn(c, 9 * c, device=dev) / (3 * c ** 0.5)).bfloat16()
         res = torch.randn(B, hw, hw, c, device=dev).bfloat16()

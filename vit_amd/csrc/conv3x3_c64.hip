@@ -77,6 +77,9 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
   const int fr = lane & 15, fq = lane >> 4;
   const int flip = p.transposed;
   const int G = gridDim.x;
+  // Workgroup b runs on XCD b % 8: give each XCD a run of consecutive tiles per round, so that the two halo rows a
+  // tile shares with its vertical neighbour are fetched by CUs behind the same L2 at about the same time.
+  const int vb = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_page_l1);
 
 #define L1_DMA(desc_, tt_, pass_, buf_)                                                                  \
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
       const int stap = flip ? 8 - tap : tap;
       glds16(p.B + (long)row * p.ldb + stap * 64 + chunk * 8, wts + pw * 1024);
     }
-    const int tt0 = blockIdx.x;
+    const int tt0 = vb;
     if (tt0 < ntiles) {
 #pragma unroll 1
       for (int pass = wave; pass < L1_PASSES; pass += L1_WAVES) {
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
     for (int pass = 0; pass < L1_PASSES; ++pass) desc[pass] = l1_desc(pass * 8 + (lane >> 3), lane & 7);
     int buf = 0;
 #pragma unroll 1
-    for (int tt = blockIdx.x; tt < ntiles; tt += G, buf ^= 1) {
+    for (int tt = vb; tt < ntiles; tt += G, buf ^= 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the patch of tile tt landed ...
       __builtin_amdgcn_s_barrier();                      // ... and every compute wave finished reading the other buffer
       asm volatile("" ::: "memory");
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
 
   int buf = 0;
 #pragma unroll 1
-  for (int tt = blockIdx.x; tt < ntiles; tt += G, buf ^= 1) {
+  for (int tt = vb; tt < ntiles; tt += G, buf ^= 1) {
     // the producer arrives here only after this tile's patch landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
