@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 4
+#define RVIT_ABI_VERSION 5
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -225,14 +225,17 @@ int rvit_batch_sum_f32(const float* x, int64_t ldb, float* out, int B, int64_t n
  * unbiased for running_var, momentum update like torch).  C % 8 == 0, 256 % (C/8) == 0.
  *   rvit_bn_stats:  sums[0..C) += sum_m y, sums[C..2C) += sum_m y^2   (caller zeroes sums)
  *   rvit_bn_apply:  z = relu?( gamma*(y-mean)*rstd + beta + residual ); updates running stats
- *                   when running_mean/var are given. */
+ *                   when running_mean/var are given.  relu_mask (optional, relu only): uint8 [M, C/8],
+ *                   bit k of byte (m, c/8) = z[m, 8*(c/8) + k] > 0; lets the backward kernels read one byte per
+ *                   8 channels instead of z. */
 int rvit_bn_stats(const void* y, int64_t M, int C, float* sums, void* stream);
 int rvit_bn_apply(const void* y, const float* sums, const float* gamma, const float* beta, const void* residual,
                   void* z, int64_t M, int C, float eps, int relu, float momentum, float* running_mean,
-                  float* running_var, void* stream);
+                  float* running_var, void* relu_mask, void* stream);
 
 /* Backward of the above (autograd of BatchNorm2d + ReLU + residual add):
- *   dzm = dz * (z > 0) when relu, else dz
+ *   dzm = dz * (z > 0) when relu, else dz; relu = 1: z is the forward output (bf16 map), relu = 2: z is the
+ *   relu_mask written by rvit_bn_apply
  *   rvit_bn_bwd_reduce: bwd_sums[0..C) += sum dzm, bwd_sums[C..2C) += sum dzm*xhat (caller zeroes)
  *   rvit_bn_bwd_apply:  dy = gamma*rstd*(dzm - mean(dzm) - xhat*mean(dzm*xhat)); dgamma += .., dbeta += ..;
  *                       dz_masked (optional) receives dzm = the gradient of the residual branch. */

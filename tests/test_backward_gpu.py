@@ -254,3 +254,70 @@ def test_gemm_gate_and_a_remap(dev):
     ops.gemm(tok.to(dev), w2.to(dev), o2, a_rows=B * P, a_row_group=P, a_row_extra=1)
     ref = tok.float().reshape(B, P + 1, E)[:, 1:].reshape(-1, E) @ w2.float().T
     _close(o2, ref, 1e-4, 1e-4, "A row remap")
+
+
+@pytest.mark.parametrize("M,C", [(1000, 64), (2 * 28 * 28, 128), (333, 512), (5 * 112 * 112, 64)])
+@pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False)])
+def test_batchnorm_train_fwd_bwd(dev, M, C, relu, with_res):
+    """Training-mode BatchNorm (+ residual + ReLU) forward and backward (csrc/bn.hip) against torch autograd on the
+    same bf16-rounded operands; with relu the backward is run twice, from the forward output z and from the
+    sign-bit mask `bn_apply` writes, and the two must agree bit for bit."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    y = (torch.randn(M, C, generator=g) * 1.5 + 0.3).bfloat16()
+    res = torch.randn(M, C, generator=g).bfloat16() if with_res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    dz = torch.randn(M, C, generator=g).bfloat16()
+    # reference
+    yr = y.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    mean, var = yr.mean(0), yr.var(0, unbiased=False)
+    zr = (yr - mean) / torch.sqrt(var + 1e-5) * gr + br
+    if with_res:
+        zr = zr + res.float()
+    if relu:
+        zr = torch.relu(zr)
+    zr.backward(dz.float())
+    # device
+    yd, dzd = y.to(dev).view(1, 1, M, C), dz.to(dev).view(1, 1, M, C)
+    fs = torch.zeros(2 * C, device=dev)
+    ops.bn_stats(yd, fs)
+    z = torch.empty_like(yd)
+    mask = torch.zeros(M * (C // 8), dtype=torch.uint8, device=dev) if relu else None
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ops.bn_apply(yd, fs, gamma.to(dev), beta.to(dev), z, eps=1e-5, relu=relu,
+                 residual=None if res is None else res.to(dev).view(1, 1, M, C), running_mean=rm, running_var=rv,
+                 relu_mask=mask)
+    assert (z.view(M, C).float().cpu() - zr.detach()).abs().max().item() <= 2.0 ** -7 * max(1.0, zr.abs().max().item())
+    assert torch.allclose(rm.cpu(), 0.1 * mean.detach(), atol=1e-4)
+    assert torch.allclose(rv.cpu(), 0.9 + 0.1 * yr.detach().var(0, unbiased=True), rtol=1e-3, atol=1e-4)
+    if relu:
+        bits = ((mask.view(M, C // 8, 1) >> torch.arange(8, device=dev, dtype=torch.uint8)) & 1).view(M, C).bool()
+        assert torch.equal(bits, z.view(M, C) > 0)
+
+    def backward(**kw):
+        bs = torch.zeros(2 * C, device=dev)
+        dy = torch.empty_like(yd)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dzm = torch.empty_like(yd)
+        ops.bn_bwd(dzd, kw.get("z"), yd, fs, bs, gamma.to(dev), dy, dg, db, eps=1e-5, relu=relu, dz_masked=dzm,
+                   relu_mask=kw.get("relu_mask"))
+        return dy, dg, db, dzm
+
+    dy, dg, db, dzm = backward(z=z)
+    scale = max(1.0, yr.grad.abs().max().item())
+    assert (dy.view(M, C).float().cpu() - yr.grad).abs().max().item() <= 0.02 * scale
+    assert torch.allclose(dg.cpu(), gr.grad, rtol=2e-2, atol=0.05 * max(1.0, gr.grad.abs().max().item()) * 0.1 + 0.5)
+    assert torch.allclose(db.cpu(), br.grad, rtol=2e-2, atol=0.5)
+    if relu:
+        dy2, dg2, db2, dzm2 = backward(relu_mask=mask)
+        # the masked gradient is identical; the per-channel sums are float atomics (same addends, order may differ),
+        # so dy may move by an ulp of bf16
+        assert torch.equal(dzm, dzm2)
+        assert (dy.float() - dy2.float()).abs().max().item() <= 2.0 ** -7 * scale
+        assert torch.allclose(dg, dg2, rtol=1e-4, atol=1e-2) and torch.allclose(db, db2, rtol=1e-4, atol=1e-2)
+        with pytest.raises(ValueError):
+            ops.bn_bwd(dzd, None, yd, fs, torch.zeros(2 * C, device=dev), gamma.to(dev), dy, dg, db, eps=1e-5, relu=True)
+        with pytest.raises(ValueError):
+            ops.bn_bwd(dzd, None, yd, fs, torch.zeros(2 * C, device=dev), gamma.to(dev), dy, dg, db, eps=1e-5, relu=True,
+                       relu_mask=mask[:-1])

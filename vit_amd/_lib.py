@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -65,7 +65,7 @@ SIGNATURES = {
     "rvit_preprocess_u8": ([P, I, I, I, I, P, P, I, P, P, I, I, P, I, P, F, U64, P, P], c_int),
     "rvit_transpose_batched_bf16": ([P, P, P, I, L, P], c_int),
     "rvit_bn_stats": ([P, L, I, P, P], c_int),
-    "rvit_bn_apply": ([P, P, P, P, P, P, L, I, F, I, F, P, P, P], c_int),
+    "rvit_bn_apply": ([P, P, P, P, P, P, L, I, F, I, F, P, P, P, P], c_int),
     "rvit_bn_bwd_reduce": ([P, P, P, P, L, I, F, I, P, P], c_int),
     "rvit_bn_bwd_apply": ([P, P, P, P, P, P, P, P, P, P, L, I, F, I, P], c_int),
     "rvit_maxpool3x3s2_bwd_nhwc": ([P, P, P, I, I, I, I, P], c_int),

@@ -11,9 +11,9 @@ int rvit_bn_stats(const void* y, int64_t M, int C, float* sums, void* stream) {
 
 int rvit_bn_apply(const void* y, const float* sums, const float* gamma, const float* beta, const void* residual,
                   void* z, int64_t M, int C, float eps, int relu, float momentum, float* running_mean,
-                  float* running_var, void* stream) {
+                  float* running_var, void* relu_mask, void* stream) {
   return rvit_bn_apply_impl(y, sums, gamma, beta, residual, z, M, C, eps, relu, momentum, running_mean, running_var,
-                            (hipStream_t)stream);
+                            relu_mask, (hipStream_t)stream);
 }
 
 int rvit_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* fwd_sums, int64_t M, int C,

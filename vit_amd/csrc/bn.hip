@@ -25,6 +25,23 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
   return o;
 }
 
+// ReLU sign bits of 8 packed bf16 outputs (bit k = element k > 0) and their use on a gradient: the backward
+// kernels then read one byte per 8 channels instead of the 16-byte forward output they only need the sign of.
+__device__ __forceinline__ unsigned mask8(const uint4 o) {
+  unsigned m = 0;
+  const unsigned w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m |= ((short)(w[i] & 0xffffu) > 0 ? 1u : 0u) << (2 * i);
+    m |= ((int)w[i] > 0xffff ? 1u : 0u) << (2 * i + 1);
+  }
+  return m;
+}
+__device__ __forceinline__ void apply_mask8(float (&d)[8], unsigned m) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[k] = (m >> k) & 1u ? d[k] : 0.f;
+}
+
 // grid-stride row partition shared by the reduction kernels
 struct RowSpan { long m0, m1; int chunk, r, rows_per_pass; };
 __device__ __forceinline__ RowSpan row_span(long M, int C, int threads = 256) {
@@ -105,8 +122,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
                                                        const bf16* __restrict__ res, bf16* __restrict__ z, long M, int C,
                                                        float eps, int relu, float momentum,
                                                        float* __restrict__ running_mean,
-                                                       float* __restrict__ running_var) {
+                                                       float* __restrict__ running_var,
+                                                       uint8_t* __restrict__ mask) {
   const RowSpan s = row_span(M, C);
+  const int cpr = C >> 3;
   const long step = s.rows_per_pass;
   const int c0 = s.chunk * 8;
   const float inv_m = 1.0f / (float)M;
@@ -148,7 +167,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], lo);
-      *reinterpret_cast<uint4*>(z + (m + j * step) * C + c0) = pack8(v);
+      const uint4 o = pack8(v);
+      *reinterpret_cast<uint4*>(z + (m + j * step) * C + c0) = o;
+      if (mask) mask[(m + j * step) * cpr + s.chunk] = (uint8_t)mask8(o);
     }
   }
   for (; m < s.m1; m += step) {
@@ -165,7 +186,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], lo);
-    *reinterpret_cast<uint4*>(z + o) = pack8(v);
+    const uint4 ov = pack8(v);
+    *reinterpret_cast<uint4*>(z + o) = ov;
+    if (mask) mask[m * cpr + s.chunk] = (uint8_t)mask8(ov);
   }
 }
 
@@ -179,7 +202,8 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
   __syncthreads();
   const RowSpan s = row_span(M, C, RED_THREADS);
   const long step = s.rows_per_pass;
-  const int c0 = s.chunk * 8;
+  const int c0 = s.chunk * 8, cpr = C >> 3;
+  const uint8_t* __restrict__ zmask = reinterpret_cast<const uint8_t*>(z);   // relu == 2: sign bits, not the map
   const float inv_m = 1.0f / (float)M;
   float mean[8], s1[8], s2[8];
 #pragma unroll
@@ -191,24 +215,27 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
   long m = s.m0 + s.r;
   for (; m + step < s.m1; m += 2 * step) {
     uint4 du[2], yu[2], zu[2];
+    unsigned mu[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const long o = (m + j * step) * C + c0;
       du[j] = *reinterpret_cast<const uint4*>(dz + o);
       yu[j] = *reinterpret_cast<const uint4*>(y + o);
-      if (relu) zu[j] = *reinterpret_cast<const uint4*>(z + o);
+      if (relu == 1) zu[j] = *reinterpret_cast<const uint4*>(z + o);
+      if (relu == 2) mu[j] = zmask[(m + j * step) * cpr + s.chunk];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float d[8], yv[8];
       unpack8(du[j], d);
       unpack8(yu[j], yv);
-      if (relu) {
+      if (relu == 1) {
         float zv[8];
         unpack8(zu[j], zv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
       }
+      if (relu == 2) apply_mask8(d, mu[j]);
 #pragma unroll
       for (int k = 0; k < 8; ++k) { s1[k] += d[k]; s2[k] += d[k] * (yv[k] - mean[k]); }
     }
@@ -218,12 +245,13 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
     float d[8], yv[8];
     unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
     unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
-    if (relu) {
+    if (relu == 1) {
       float zv[8];
       unpack8(*reinterpret_cast<const uint4*>(z + o), zv);
 #pragma unroll
       for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
     }
+    if (relu == 2) apply_mask8(d, zmask[m * cpr + s.chunk]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] += d[k]; s2[k] += d[k] * (yv[k] - mean[k]); }
   }
@@ -246,7 +274,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
                                                            int relu) {
   const RowSpan s = row_span(M, C);
   const long step = s.rows_per_pass;
-  const int c0 = s.chunk * 8;
+  const int c0 = s.chunk * 8, cpr = C >> 3;
+  const uint8_t* __restrict__ zmask = reinterpret_cast<const uint8_t*>(z);   // relu == 2: sign bits, not the map
   const float inv_m = 1.0f / (float)M;
   // dy = a*dzm + b*y + c  with a = gamma*rstd, b = -a*rstd*bs2/M, c = -a*bs1/M - b*mean
   float ca[8], cb[8], cc[8];
@@ -268,12 +297,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
   long m = s.m0 + s.r;
   for (; m + step < s.m1; m += 2 * step) {
     uint4 du[2], yu[2], zu[2];
+    unsigned mu[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const long o = (m + j * step) * C + c0;
       du[j] = *reinterpret_cast<const uint4*>(dz + o);
       yu[j] = *reinterpret_cast<const uint4*>(y + o);
-      if (relu) zu[j] = *reinterpret_cast<const uint4*>(z + o);
+      if (relu == 1) zu[j] = *reinterpret_cast<const uint4*>(z + o);
+      if (relu == 2) mu[j] = zmask[(m + j * step) * cpr + s.chunk];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -281,12 +312,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
       float d[8], yv[8], out[8];
       unpack8(du[j], d);
       unpack8(yu[j], yv);
-      if (relu) {
+      if (relu == 1) {
         float zv[8];
         unpack8(zu[j], zv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
       }
+      if (relu == 2) apply_mask8(d, mu[j]);
       if (dzm_out) *reinterpret_cast<uint4*>(dzm_out + o) = pack8(d);
 #pragma unroll
       for (int k = 0; k < 8; ++k) out[k] = ca[k] * d[k] + cb[k] * yv[k] + cc[k];
@@ -298,12 +330,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
     float d[8], yv[8], out[8];
     unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
     unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
-    if (relu) {
+    if (relu == 1) {
       float zv[8];
       unpack8(*reinterpret_cast<const uint4*>(z + o), zv);
 #pragma unroll
       for (int k = 0; k < 8; ++k) d[k] = zv[k] > 0.f ? d[k] : 0.f;
     }
+    if (relu == 2) apply_mask8(d, zmask[m * cpr + s.chunk]);
     if (dzm_out) *reinterpret_cast<uint4*>(dzm_out + o) = pack8(d);
 #pragma unroll
     for (int k = 0; k < 8; ++k) out[k] = ca[k] * d[k] + cb[k] * yv[k] + cc[k];
@@ -380,13 +413,15 @@ int rvit_bn_stats_impl(const void* y, long M, int C, float* sums, hipStream_t st
 
 int rvit_bn_apply_impl(const void* y, const float* sums, const float* gamma, const float* beta, const void* res,
                        void* z, long M, int C, float eps, int relu, float momentum, float* running_mean,
-                       float* running_var, hipStream_t st) {
+                       float* running_var, void* relu_mask, hipStream_t st) {
   RVIT_CHECK_ARG(y && sums && gamma && beta && z && bn_shape_ok(M, C), "bn_apply: bad arguments");
   RVIT_CHECK_ARG(rvit_aligned16(y) && rvit_aligned16(z) && (!res || rvit_aligned16(res)), "bn_apply: alignment");
   RVIT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_apply: running stats come in pairs");
+  RVIT_CHECK_ARG(!relu_mask || relu, "bn_apply: a ReLU mask needs relu");
   const long blocks = bn_blocks(M, C, 8);
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)y, sums,
-                     gamma, beta, (const bf16*)res, (bf16*)z, M, C, eps, relu, momentum, running_mean, running_var);
+                     gamma, beta, (const bf16*)res, (bf16*)z, M, C, eps, relu, momentum, running_mean, running_var,
+                     (uint8_t*)relu_mask);
   RVIT_CHECK_LAUNCH("bn_apply");
   return RVIT_OK;
 }
@@ -394,7 +429,8 @@ int rvit_bn_apply_impl(const void* y, const float* sums, const float* gamma, con
 int rvit_bn_bwd_reduce_impl(const void* dz, const void* z, const void* y, const float* fsums, long M, int C, float eps,
                             int relu, float* bsums, hipStream_t st) {
   RVIT_CHECK_ARG(dz && y && fsums && bsums && (!relu || z) && bn_shape_ok(M, C), "bn_bwd_reduce: bad arguments");
-  RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && (!z || rvit_aligned16(z)), "bn_bwd_reduce: alignment");
+  RVIT_CHECK_ARG(relu >= 0 && relu <= 2, "bn_bwd_reduce: relu is 0, 1 (z = forward output) or 2 (z = sign bits)");
+  RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && (relu != 1 || rvit_aligned16(z)), "bn_bwd_reduce: alignment");
   const long blocks = red_blocks(M, C);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), 2 * C * sizeof(float), st,
                      (const bf16*)dz, (const bf16*)z, (const bf16*)y, fsums, M, C, eps, relu, bsums);
@@ -407,7 +443,8 @@ int rvit_bn_bwd_apply_impl(const void* dz, const void* z, const void* y, const f
                            float eps, int relu, hipStream_t st) {
   RVIT_CHECK_ARG(dz && y && fsums && bsums && gamma && dy && dgamma && dbeta && (!relu || z) && bn_shape_ok(M, C),
                  "bn_bwd_apply: bad arguments");
-  RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && rvit_aligned16(dy) && (!z || rvit_aligned16(z)) &&
+  RVIT_CHECK_ARG(relu >= 0 && relu <= 2, "bn_bwd_apply: relu is 0, 1 (z = forward output) or 2 (z = sign bits)");
+  RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && rvit_aligned16(dy) && (relu != 1 || rvit_aligned16(z)) &&
                      (!dzm_out || rvit_aligned16(dzm_out)),
                  "bn_bwd_apply: alignment");
   const long blocks = bn_blocks(M, C, 8);

@@ -581,9 +581,13 @@ def bn_stats(y: torch.Tensor, sums: torch.Tensor) -> torch.Tensor:
 
 def bn_apply(y: torch.Tensor, sums: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, z: torch.Tensor, *,
              eps: float, relu: bool, residual: Optional[torch.Tensor] = None, momentum: float = 0.1,
-             running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _need_cuda(y, sums, gamma, beta, z, residual, running_mean, running_var)
+             running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None,
+             relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """relu_mask (optional, with relu): uint8 [M * C/8] receiving the sign bits of z (bit k of byte (m, c/8) =
+    z[m, 8*(c/8)+k] > 0); `bn_bwd(..., relu_mask=...)` then reads it instead of z."""
+    _need_cuda(y, sums, gamma, beta, z, residual, running_mean, running_var, relu_mask)
     M, C = _map2d(y, "bn_apply y")
+    _check_relu_mask(relu_mask, M, C, relu)
     if z.shape != y.shape or _map2d(z, "bn_apply z") != (M, C) or (residual is not None and residual.shape != y.shape):
         raise ValueError("bn_apply: shape mismatch")
     if residual is not None:
@@ -593,31 +597,45 @@ def bn_apply(y: torch.Tensor, sums: torch.Tensor, gamma: torch.Tensor, beta: tor
     with _Span("bn_apply", 0, _nbytes(y, z, residual)):
         check(_lib.load().rvit_bn_apply(y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                         _ptr(residual), z.data_ptr(), M, C, eps, int(relu), momentum,
-                                        _ptr(running_mean), _ptr(running_var), _stream()), "rvit_bn_apply")
+                                        _ptr(running_mean), _ptr(running_var), _ptr(relu_mask), _stream()),
+              "rvit_bn_apply")
     return z
+
+
+def _check_relu_mask(mask, M, C, relu):
+    if mask is None:
+        return
+    if not relu:
+        raise ValueError("bn: a ReLU mask needs relu=True")
+    if mask.dtype != torch.uint8 or not mask.is_contiguous() or mask.numel() != M * (C // 8):
+        raise ValueError("bn: relu_mask must be a contiguous uint8 tensor of M * C/8 bytes")
 
 
 def bn_bwd(dz: torch.Tensor, z: Optional[torch.Tensor], y: torch.Tensor, fwd_sums: torch.Tensor,
            bwd_sums: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, *,
-           eps: float, relu: bool, dz_masked: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Both BatchNorm backward passes (reduce, then apply); bwd_sums must be zero on entry."""
-    _need_cuda(dz, z, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, dz_masked)
+           eps: float, relu: bool, dz_masked: Optional[torch.Tensor] = None,
+           relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Both BatchNorm backward passes (reduce, then apply); bwd_sums must be zero on entry.  With relu the sign of
+    the forward output comes from `relu_mask` (the bits `bn_apply` wrote) when given, else from z."""
+    _need_cuda(dz, z, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, dz_masked, relu_mask)
     M, C = _map2d(y, "bn_bwd y")
+    _check_relu_mask(relu_mask, M, C, relu)
     for t in (dz, dy, z, dz_masked):
         if t is not None and (t.shape != y.shape or _map2d(t, "bn_bwd map") != (M, C)):
             raise ValueError("bn_bwd: shape mismatch")
-    if relu and z is None:
-        raise ValueError("bn_bwd: relu needs the forward output z")
+    if relu and z is None and relu_mask is None:
+        raise ValueError("bn_bwd: relu needs the forward output z or its sign bits")
+    mode, zsrc = (2, relu_mask) if (relu and relu_mask is not None) else (int(relu), z)
     for v, n in ((fwd_sums, 2 * C), (bwd_sums, 2 * C), (gamma, C), (dgamma, C), (dbeta, C)):
         _vec_f32(v, n, "bn_bwd: vector")
     lib = _lib.load()
     with _Span("bn_bwd_reduce", 0, _nbytes(dz, y, z if relu else None)):
-        check(lib.rvit_bn_bwd_reduce(dz.data_ptr(), _ptr(z), y.data_ptr(), fwd_sums.data_ptr(), M, C, eps, int(relu),
+        check(lib.rvit_bn_bwd_reduce(dz.data_ptr(), _ptr(zsrc), y.data_ptr(), fwd_sums.data_ptr(), M, C, eps, mode,
                                      bwd_sums.data_ptr(), _stream()), "rvit_bn_bwd_reduce")
-    with _Span("bn_bwd_apply", 0, _nbytes(dz, y, z if relu else None, dy, dz_masked)):
-        check(lib.rvit_bn_bwd_apply(dz.data_ptr(), _ptr(z), y.data_ptr(), fwd_sums.data_ptr(), bwd_sums.data_ptr(),
+    with _Span("bn_bwd_apply", 0, _nbytes(dz, y, zsrc if relu else None, dy, dz_masked)):
+        check(lib.rvit_bn_bwd_apply(dz.data_ptr(), _ptr(zsrc), y.data_ptr(), fwd_sums.data_ptr(), bwd_sums.data_ptr(),
                                     gamma.data_ptr(), dy.data_ptr(), _ptr(dz_masked), dgamma.data_ptr(),
-                                    dbeta.data_ptr(), M, C, eps, int(relu), _stream()), "rvit_bn_bwd_apply")
+                                    dbeta.data_ptr(), M, C, eps, mode, _stream()), "rvit_bn_bwd_apply")
     return dy
 
 

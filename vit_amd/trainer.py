@@ -308,6 +308,8 @@ class TrainEngine:
             b["img"] = torch.zeros(B, 230, 232, 4, **z)
             b["c1_y"] = torch.empty(B, 112, 112, 64, **z)
             b["c1_z"] = torch.empty(B, 112, 112, 64, **z)
+            # sign bits of the ReLU outputs (one byte per 8 channels): what the BatchNorm backward reads instead of z
+            b["c1_m"] = torch.empty(B * 112 * 112 * 8, dtype=torch.uint8, device=dev)
             b["pool"] = torch.empty(B, 56, 56, 64, **z)
             b["pool_arg"] = torch.empty(B, 56, 56, 64, dtype=torch.uint8, device=dev)
             blocks = []
@@ -317,6 +319,8 @@ class TrainEngine:
                 s, co = blk.conv1.stride, blk.conv1.cout
                 hw //= s
                 d = {nm: torch.empty(B, hw, hw, co, **z) for nm in ("y1", "z1", "y2", "zo")}
+                d["m1"] = torch.empty(B * hw * hw * (co // 8), dtype=torch.uint8, device=dev)
+                d["mo"] = torch.empty(B * hw * hw * (co // 8), dtype=torch.uint8, device=dev)
                 if blk.downsample is not None:
                     d["yd"] = torch.empty(B, hw, hw, co, **z)
                     d["zd"] = torch.empty(B, hw, hw, co, **z)
@@ -367,11 +371,11 @@ class TrainEngine:
     def _bn_params(self, bn):
         return bn.weight.detach(), bn.bias.detach()
 
-    def _conv_bn(self, x, w, y, z, bn, fs, *, kh, stride, pad, relu, residual=None, seg_len=None, kw=None):
+    def _conv_bn(self, x, w, y, z, bn, fs, *, kh, stride, pad, relu, residual=None, seg_len=None, kw=None, mask=None):
         ops.conv2d(x, w, y, kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, seg_len=seg_len)
         ops.bn_stats(y, fs)
         ops.bn_apply(y, fs, bn.weight.detach(), bn.bias.detach(), z, eps=bn.eps, relu=relu, residual=residual,
-                     momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var)
+                     momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, relu_mask=mask)
         bn.num_batches_tracked += 1
 
     def _stem_forward(self, P, b, B) -> torch.Tensor:
@@ -380,7 +384,7 @@ class TrainEngine:
         off = 0
         fs = b["fsums"]
         self._conv_bn(b["img"], P["conv1_w"], b["c1_y"], b["c1_z"], cb.bn1, fs[off:off + 128], kh=7, kw=1, stride=2,
-                      pad=0, relu=True, seg_len=32)
+                      pad=0, relu=True, seg_len=32, mask=b["c1_m"])
         off += 128
         ops.maxpool3x3s2(b["c1_z"], b["pool"], b["pool_arg"])
         cur = b["pool"]
@@ -389,7 +393,7 @@ class TrainEngine:
             d["in"] = cur
             d["fs_off"] = off
             self._conv_bn(cur, pk["c1_w"], d["y1"], d["z1"], blk.bn1, fs[off:off + 2 * co], kh=3, stride=s, pad=1,
-                          relu=True)
+                          relu=True, mask=d["m1"])
             off += 2 * co
             idn = cur
             if "ds_w" in pk:
@@ -397,7 +401,7 @@ class TrainEngine:
                               kh=1, stride=s, pad=0, relu=False)
                 idn = d["zd"]
             self._conv_bn(d["z1"], pk["c2_w"], d["y2"], d["zo"], blk.bn2, fs[off:off + 2 * co], kh=3, stride=1, pad=1,
-                          relu=True, residual=idn)
+                          relu=True, residual=idn, mask=d["mo"])
             off += 2 * co * (2 if "ds_w" in pk else 1)
             cur = d["zo"]
         return cur
@@ -486,16 +490,17 @@ class TrainEngine:
             bd = bs_all[off + 4 * co:off + 6 * co] if has_ds else None
             dy2 = self._scratch(b, ("dy", co, d["y2"].shape[1]), d["y2"])
             dzm = self._scratch(b, ("dzm", co, d["y2"].shape[1]), d["y2"])
-            ops.bn_bwd(dz, d["zo"], d["y2"], f2, b2, blk.bn2.weight.detach(), dy2,
+            ops.bn_bwd(dz, None, d["y2"], f2, b2, blk.bn2.weight.detach(), dy2,
                        self._g(flat, pref + "bn2.weight"), self._g(flat, pref + "bn2.bias"), eps=blk.bn2.eps, relu=True,
-                       dz_masked=dzm)
+                       dz_masked=dzm, relu_mask=d["mo"])
             ops.conv2d_wgrad(dy2, d["z1"], self._g(flat, pref + "conv2.weight").view(co, 9 * co), kh=3, kw=3, stride=1,
                              pad=1)
             dz1 = self._scratch(b, ("dz1", co, d["y2"].shape[1]), d["y2"])
             ops.conv2d_dgrad(dy2, pk["c2_wt"], dz1, kh=3, kw=3, stride=1, pad=1)
             dy1 = dy2  # dy2 is dead now
-            ops.bn_bwd(dz1, d["z1"], d["y1"], f1, b1, blk.bn1.weight.detach(), dy1,
-                       self._g(flat, pref + "bn1.weight"), self._g(flat, pref + "bn1.bias"), eps=blk.bn1.eps, relu=True)
+            ops.bn_bwd(dz1, None, d["y1"], f1, b1, blk.bn1.weight.detach(), dy1,
+                       self._g(flat, pref + "bn1.weight"), self._g(flat, pref + "bn1.bias"), eps=blk.bn1.eps, relu=True,
+                       relu_mask=d["m1"])
             xin = d["in"]
             ops.conv2d_wgrad(dy1, xin, self._g(flat, pref + "conv1.weight").view(co, 9 * ci), kh=3, kw=3, stride=s,
                              pad=1)
@@ -519,9 +524,9 @@ class TrainEngine:
         dc1 = self._scratch(b, ("dc1",), b["c1_z"])
         ops.maxpool3x3s2_bwd(dz, b["pool_arg"], dc1)
         dyc = self._scratch(b, ("dyc",), b["c1_z"])
-        ops.bn_bwd(dc1, b["c1_z"], b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(), dyc,
+        ops.bn_bwd(dc1, None, b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(), dyc,
                    self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"), eps=cb.bn1.eps,
-                   relu=True)
+                   relu=True, relu_mask=b["c1_m"])
         dw1 = torch.zeros(64, 224, dtype=F32, device=dyc.device)
         ops.conv2d_wgrad(dyc, b["img"], dw1, kh=7, kw=1, stride=2, pad=0, seg_len=32)
         self._g(flat, "cnn_backbone.conv1.weight").view(64, 7, 7, 3).copy_(dw1.view(64, 7, 8, 4)[:, :, :7, :3])
