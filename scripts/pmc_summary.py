@@ -30,4 +30,10 @@ for d in sys.argv[1:]:
                 acc[key][1].add(row["Dispatch_Id"])
         for (k, c), (tot, disp) in sorted(acc.items()):
             n = max(1, len(disp))
-            print(f"{k:90s} {c:12s} launches {n:6d} avg_per_launch {tot / n:16.1f}")
+            print(f"{k:90s} {c:26s} launches {n:6d} avg_per_launch {tot / n:16.1f}")
+        # MFMA pipe occupancy where the pass holds both counters (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+        kernels = sorted({k for (k, c) in acc if c == "SQ_VALU_MFMA_BUSY_CYCLES"})
+        for k in kernels:
+            if (k, "GRBM_GUI_ACTIVE") in acc and acc[(k, "GRBM_GUI_ACTIVE")][0] > 0:
+                util = 8.0 * acc[(k, "SQ_VALU_MFMA_BUSY_CYCLES")][0] / (acc[(k, "GRBM_GUI_ACTIVE")][0] * 1024.0)
+                print(f"{k:90s} mfma_pipe_busy_fraction {util:8.4f}")
