@@ -88,6 +88,32 @@ def test_batch_invariance_and_repeatability(dev):
     assert torch.allclose(full[4:5], one, atol=1e-5, rtol=0)
 
 
+def test_empty_and_odd_batches(dev):
+    """Edge cases of the module contract: an empty batch gives an empty result in eval() (as the reference's torch
+    modules do) and is refused in train() (BatchNorm: "Expected more than 1 value per channel"); odd batch sizes
+    (tiles straddle images, short last tiles) agree with the same frames run one by one."""
+    from vit_amd.synth import micro_doppler_batch
+    m, _, _ = _pair(CASES[0][1], seed=2, dev=dev)
+    empty = torch.zeros(0, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        assert tuple(m(empty).shape) == (0, m.num_classes)
+        assert tuple(m.forward_features(empty).shape) == (0, m.embed_dim)
+        x = micro_doppler_batch(7, seed=11).to(dev)
+        full = m(x).clone()
+        for i in (0, 3, 6):
+            assert torch.allclose(full[i:i + 1], m(x[i:i + 1]), atol=1e-5, rtol=0)
+    m.train()
+    try:
+        with pytest.raises(ValueError):
+            m(empty)
+    finally:
+        m.eval()
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 1, 224, 224, device=dev))
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, 200, 224, device=dev))
+
+
 def test_cpu_input_raises(dev):
     m, _, _ = _pair(CASES[0][1], seed=2, dev=dev)
     with pytest.raises(RuntimeError):

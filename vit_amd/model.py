@@ -238,6 +238,11 @@ class CNNViTHybrid(nn.Module):
 
     def _run(self, x, features_only: bool):
         x = self._check_input(x)
+        if x.shape[0] == 0:
+            # an empty batch: torch modules return an empty result in eval() and BatchNorm refuses it in train()
+            if self.training and self.cnn_backbone is not None:
+                raise ValueError("Expected more than 1 value per channel when training, got an empty batch")
+            return x.new_zeros((0, self.embed_dim if features_only else self.num_classes), dtype=torch.float32)
         if self.training:
             # train(): BatchNorm batch statistics; backward on librvit when gradients are recorded.
             # A training forward means the weights are about to change: the inference engine re-packs next time
