@@ -25,7 +25,9 @@ def _close(got, ref, rtol, atol, what=""):
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(1000, 256, 256, 0), (777, 768, 264, 3), (64, 16, 128, 1), (5000, 1024, 256, 0),
-                                          (300, 136, 72, 2)])
+                                          (300, 136, 72, 2),
+                                          # >= 32 M tiles per split: the eight-wave variant (ragged M, partial N / K tiles)
+                                          (4100, 256, 384, 1), (5000, 1024, 256, 2), (3000, 136, 200, 1)])
 def test_wgrad_plain(dev, M, N, K, splits):
     from vit_amd import ops
     g = torch.Generator().manual_seed(M + N + K)

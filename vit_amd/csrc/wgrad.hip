@@ -49,11 +49,18 @@ constexpr int TILE_B = TM * 256;   // bytes of one operand tile (64 rows x 128 b
 // NARROW (N <= 64, the 64-channel stem layers): only the first 64 columns of the dY tile are real, so
 // instead of idling two waves on zero rows the wave pairs split the 64-row M tile in halves (32 rows
 // each) over the same 64(n) x 128(k) output; the atomics of the epilogue add the two halves.
-template <bool GATHER, bool NARROW>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p, int ntiles, int nsplits) {
+// W8 (not NARROW): eight waves; waves 0-3 contract rows 0-31 of every 64-row M tile, waves 4-7 rows 32-63, each group
+// over the full 128 x 128 output (the epilogue's atomics add the two halves).  Twice the waves per SIMD (4 with two
+// workgroups per CU), half the LDS-DMA instructions and half the MFMAs per wave between two barriers.
+template <bool GATHER, bool NARROW, bool W8>
+__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(const WgradArgs p, int ntiles, int nsplits) {
+  static_assert(!(NARROW && W8), "the narrow variant stays on four waves");
+  constexpr int NPASS = W8 ? 2 : 4;            // DMA passes per operand tile
+  constexpr int PASS_ROWS = TM / NPASS;        // rows per pass (one 16-byte chunk slot per thread)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (dY tile + X tile)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wn = NARROW ? 0 : wave >> 1, wk = wave & 1;  // wave's 64x64 quadrant of the 128x128 output tile
+  const int wq = W8 ? (wave & 3) : wave;
+  const int wn = NARROW ? 0 : wq >> 1, wk = wq & 1;  // wave's 64x64 quadrant of the 128x128 output tile
 
   // workgroup -> (output tile, M split), tiles fastest.  (Pinning a split's tiles to one XCD so its L2
   // serves their re-reads was measured and is 5-15 % SLOWER on the stem shapes: profiles/r01_wgrad_splits.txt.)
@@ -98,8 +105,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p, int 
   do {                                                                                         \
     char* dY_dst = wave_dst + (stage) * (2 * TILE_B);                                          \
     char* dX_dst = dY_dst + TILE_B;                                                            \
-    _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                         \
-      const long m = (mt) * TM + ps * 16 + lrow;                                               \
+    _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                     \
+      const long m = (mt) * TM + ps * PASS_ROWS + lrow;                                        \
       const bool m_ok = m < p.M && (mt) < mt_end;                                              \
       long yr = m;                                                                             \
       if (p.y_row_group > 0) {                                                                 \
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p, int 
         yr = gy * (p.y_row_group + p.y_row_extra) + (m - gy * p.y_row_group) + p.y_row_extra;  \
       }                                                                                        \
       const bf16* ysrc = (m_ok && n_ok) ? p.dY + yr * p.ldy + ncol : zero_src;                 \
-      glds16(ysrc, dY_dst + ps * 4096);                                                        \
+      glds16(ysrc, dY_dst + ps * (PASS_ROWS * 256));                                           \
       const bf16* xsrc = zero_src;                                                             \
       if constexpr (GATHER) {                                                                  \
         if (m_ok && k_ok) {                                                                    \
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p, int 
           xsrc = p.X + xr * p.ldx + kcol;                                                      \
         }                                                                                      \
       }                                                                                        \
-      glds16(xsrc, dX_dst + ps * 4096);                                                        \
+      glds16(xsrc, dX_dst + ps * (PASS_ROWS * 256));                                           \
     }                                                                                          \
   } while (0)
 
@@ -156,8 +163,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs p, int 
     const char* sY = smem + stage * (2 * TILE_B);
     const char* sX = sY + TILE_B;
 #pragma unroll
-    for (int ks0 = 0; ks0 < (NARROW ? 1 : 2); ++ks0) {
-      const int ks = NARROW ? (wave >> 1) : ks0;
+    for (int ks0 = 0; ks0 < ((NARROW || W8) ? 1 : 2); ++ks0) {
+      const int ks = NARROW ? (wave >> 1) : W8 ? (wave >> 2) : ks0;
       bf16x8 yf[4], xf[4];
       const int rbase = (ks * 32 + rd_row) * 256 + rd_byte;
 #pragma unroll
@@ -251,12 +258,31 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
   const size_t lds = 2 * 2 * TILE_B;  // 64 KB
   dim3 grid((unsigned)(tiles * splits));
   const bool narrow = a.N <= 64;
-  if (a.mode == 1) {
-    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
-    else hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+  // Eight waves pay when a workgroup owns a long M range (ViT-B/L Linears: 20.2 vs 21.9 ms of weight gradients per
+  // ViT-B step); with few M tiles per split the doubled epilogue atomics cost more than the main loop gains
+  // (the E=256 encoder: 46 -> 71 us), and the gather variants gain nothing.
+  const bool w8 = a.mode == 0 && (mtiles + splits - 1) / splits >= 32;
+  if (!narrow && w8) {
+    // eight waves: the wave-private epilogue staging (8 x 32 rows x 272 B) is what sizes the LDS
+    const size_t lds8 = 8 * 32 * (64 * 4 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)wgrad_bf16_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+      hipError_t e2 = hipFuncSetAttribute((const void*)wgrad_bf16_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+      if (e1 != hipSuccess || e2 != hipSuccess) {
+        rvit_set_error("wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds8);
+        return RVIT_ELAUNCH;
+      }
+      attr_set = true;
+    }
+    if (a.mode == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, true>), grid, dim3(512), lds8, st, a, (int)tiles, (int)splits);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, true>), grid, dim3(512), lds8, st, a, (int)tiles, (int)splits);
+  } else if (a.mode == 1) {
+    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
   } else {
-    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
-    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
   }
   RVIT_CHECK_LAUNCH("wgrad_bf16");
   return RVIT_OK;
