@@ -233,6 +233,14 @@ int rvit_bn_apply(const void* y, const float* sums, const float* gamma, const fl
                   void* z, int64_t M, int C, float eps, int relu, float momentum, float* running_mean,
                   float* running_var, void* relu_mask, void* stream);
 
+/* Stem entry in train(): rvit_bn_apply with relu, followed by MaxPool2d(3, 2, 1), in one pass (timm resnet
+ * bn1 -> act1 -> maxpool, train_vit.py:87): y [B, H, W, C] -> pooled [B, Ho, Wo, C] (Ho = (H-1)/2+1), argmax uint8
+ * of the same shape (window tap 0..8, first maximum, as rvit_maxpool3x3s2_nhwc records it) and the relu_mask of the
+ * normalised map, which itself is never written. */
+int rvit_bn_apply_pool(const void* y, const float* sums, const float* gamma, const float* beta, void* pooled,
+                       void* argmax, void* relu_mask, int B, int H, int W, int C, float eps, float momentum,
+                       float* running_mean, float* running_var, void* stream);
+
 /* Backward of the above (autograd of BatchNorm2d + ReLU + residual add):
  *   dzm = dz * (z > 0) when relu, else dz; relu = 1: z is the forward output (bf16 map), relu = 2: z is the
  *   relu_mask written by rvit_bn_apply

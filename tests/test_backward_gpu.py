@@ -323,3 +323,36 @@ def test_batchnorm_train_fwd_bwd(dev, M, C, relu, with_res):
         with pytest.raises(ValueError):
             ops.bn_bwd(dzd, None, yd, fs, torch.zeros(2 * C, device=dev), gamma.to(dev), dy, dg, db, eps=1e-5, relu=True,
                        relu_mask=mask[:-1])
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 112, 112, 64), (3, 10, 14, 64), (1, 7, 9, 128)])
+def test_bn_apply_pool_fused(dev, B, H, W, C):
+    """BatchNorm + ReLU + MaxPool2d(3,2,1) in one pass (the training stem entry) against the two-kernel path
+    (bn_apply, then maxpool3x3s2): pooled map, argmax taps, sign bits and running statistics all bit-identical;
+    odd map sizes exercise the clipped windows."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(B * H + W)
+    y = (torch.randn(B, H, W, C, generator=g) * 1.3 - 0.1).bfloat16().to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    fs = torch.zeros(2 * C, device=dev)
+    ops.bn_stats(y, fs)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    z = torch.empty_like(y)
+    m_ref = torch.zeros(B * H * W * (C // 8), dtype=torch.uint8, device=dev)
+    rm1, rv1 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ops.bn_apply(y, fs, gamma, beta, z, eps=1e-5, relu=True, running_mean=rm1, running_var=rv1, relu_mask=m_ref)
+    p_ref = torch.empty(B, Ho, Wo, C, dtype=torch.bfloat16, device=dev)
+    a_ref = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=dev)
+    ops.maxpool3x3s2(z, p_ref, a_ref)
+    p = torch.full_like(p_ref, float("nan"))
+    a = torch.full_like(a_ref, 255)
+    m = torch.full_like(m_ref, 0xAA)
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ops.bn_apply_pool(y, fs, gamma, beta, p, a, m, eps=1e-5, running_mean=rm2, running_var=rv2)
+    assert torch.equal(p, p_ref) and torch.equal(a, a_ref) and torch.equal(m, m_ref)
+    assert torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+    # and against torch
+    zr = torch.relu(torch.nn.functional.batch_norm(y.float().permute(0, 3, 1, 2).cpu(), None, None, gamma.cpu(), beta.cpu(),
+                                                   True, 0.1, 1e-5))
+    pr = torch.nn.functional.max_pool2d(zr, 3, 2, 1).permute(0, 2, 3, 1)
+    assert (p.float().cpu() - pr).abs().max().item() <= 2.0 ** -7 * max(1.0, pr.abs().max().item())

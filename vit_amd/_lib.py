@@ -66,6 +66,7 @@ SIGNATURES = {
     "rvit_transpose_batched_bf16": ([P, P, P, I, L, P], c_int),
     "rvit_bn_stats": ([P, L, I, P, P], c_int),
     "rvit_bn_apply": ([P, P, P, P, P, P, L, I, F, I, F, P, P, P, P], c_int),
+    "rvit_bn_apply_pool": ([P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P], c_int),
     "rvit_bn_bwd_reduce": ([P, P, P, P, L, I, F, I, P, P], c_int),
     "rvit_bn_bwd_apply": ([P, P, P, P, P, P, P, P, P, P, L, I, F, I, P], c_int),
     "rvit_maxpool3x3s2_bwd_nhwc": ([P, P, P, I, I, I, I, P], c_int),

@@ -16,6 +16,13 @@ int rvit_bn_apply(const void* y, const float* sums, const float* gamma, const fl
                             relu_mask, (hipStream_t)stream);
 }
 
+int rvit_bn_apply_pool(const void* y, const float* sums, const float* gamma, const float* beta, void* pooled,
+                       void* argmax, void* relu_mask, int B, int H, int W, int C, float eps, float momentum,
+                       float* running_mean, float* running_var, void* stream) {
+  return rvit_bn_apply_pool_impl(y, sums, gamma, beta, pooled, argmax, relu_mask, B, H, W, C, eps, momentum, running_mean,
+                                 running_var, (hipStream_t)stream);
+}
+
 int rvit_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* fwd_sums, int64_t M, int C,
                        float eps, int relu, float* bwd_sums, void* stream) {
   return rvit_bn_bwd_reduce_impl(dz, z, y, fwd_sums, M, C, eps, relu, bwd_sums, (hipStream_t)stream);

@@ -192,6 +192,82 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ 
   }
 }
 
+// Stem entry in train(): BatchNorm (batch statistics) + ReLU + MaxPool2d(3, 2, 1) in one pass over the conv output:
+// the normalised 112 x 112 map is never written.  One thread per (pooled pixel, 8 channels) reads the <= 9 window
+// pixels (neighbouring threads share them through the caches), normalises, rounds to bf16 exactly as bn_apply does and
+// keeps the first maximum in tap order (maxpool_kernel's rule); it also owns the 2 x 2 pixels (2ho..2ho+1, 2wo..2wo+1)
+// of its window for the ReLU sign bits the backward pass reads.  Outputs: pooled map, argmax taps, sign bits.
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const bf16* __restrict__ y, const float* __restrict__ sums,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16* __restrict__ pooled,
+                                                            uint8_t* __restrict__ argmax, uint8_t* __restrict__ mask,
+                                                            int B, int H, int W, int C, int Ho, int Wo, float eps,
+                                                            float momentum, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var) {
+  extern __shared__ float tab[];  // scale[C], shift[C]
+  const long M = (long)B * H * W;
+  const float inv_m = 1.0f / (float)M;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mean = sums[c] * inv_m;
+    const float var = fmaxf(sums[C + c] * inv_m - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    tab[c] = sc;
+    tab[C + c] = beta[c] - mean * sc;
+    if (blockIdx.x == 0 && running_mean) {
+      const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+  __syncthreads();
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c8 = C >> 3;
+  if (idx >= (long)B * Ho * Wo * c8) return;
+  const int cq = (int)(idx % c8);
+  long r = idx / c8;
+  const int wo = (int)(r % Wo);
+  r /= Wo;
+  const int ho = (int)(r % Ho);
+  const int b = (int)(r / Ho);
+  float sc[8], sh[8], best[8];
+  int arg[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = tab[cq * 8 + k];
+    sh[k] = tab[C + cq * 8 + k];
+    best[k] = -INFINITY;
+    arg[k] = 0;
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = ho * 2 - 1 + kh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = wo * 2 - 1 + kw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      const long pix = ((long)b * H + hi) * W + wi;
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(y + pix * C + cq * 8), v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k] * sc[k] + sh[k], 0.f);
+      const uint4 o = pack8(v);
+      if (kh >= 1 && kw >= 1) mask[pix * c8 + cq] = (uint8_t)mask8(o);
+      unpack8(o, v);  // the rounded values are what a max-pool over the stored map would compare
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (v[k] > best[k]) { best[k] = v[k]; arg[k] = kh * 3 + kw; }
+    }
+  }
+  const long obase = (((long)b * Ho + ho) * Wo + wo) * C + cq * 8;
+  *reinterpret_cast<uint4*>(pooled + obase) = pack8(best);
+  uint2 a;
+  a.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+  a.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+  *reinterpret_cast<uint2*>(argmax + obase) = a;
+}
+
 __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* __restrict__ dz,
                                                                     const bf16* __restrict__ z,
                                                                     const bf16* __restrict__ y,
@@ -423,6 +499,24 @@ int rvit_bn_apply_impl(const void* y, const float* sums, const float* gamma, con
                      gamma, beta, (const bf16*)res, (bf16*)z, M, C, eps, relu, momentum, running_mean, running_var,
                      (uint8_t*)relu_mask);
   RVIT_CHECK_LAUNCH("bn_apply");
+  return RVIT_OK;
+}
+
+int rvit_bn_apply_pool_impl(const void* y, const float* sums, const float* gamma, const float* beta, void* pooled,
+                            void* argmax, void* relu_mask, int B, int H, int W, int C, float eps, float momentum,
+                            float* running_mean, float* running_var, hipStream_t st) {
+  RVIT_CHECK_ARG(y && sums && gamma && beta && pooled && argmax && relu_mask && B > 0 && H > 0 && W > 0 &&
+                     bn_shape_ok((long)B * H * W, C),
+                 "bn_apply_pool: bad arguments");
+  RVIT_CHECK_ARG(rvit_aligned16(y) && rvit_aligned16(pooled) && (((uintptr_t)argmax) & 7) == 0, "bn_apply_pool: alignment");
+  RVIT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_apply_pool: running stats come in pairs");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total = (long)B * Ho * Wo * (C >> 3);
+  RVIT_CHECK_ARG((total + 255) / 256 < 0x7fffffffL, "bn_apply_pool: too many elements");
+  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 2 * C * sizeof(float), st,
+                     (const bf16*)y, sums, gamma, beta, (bf16*)pooled, (uint8_t*)argmax, (uint8_t*)relu_mask, B, H, W, C,
+                     Ho, Wo, eps, momentum, running_mean, running_var);
+  RVIT_CHECK_LAUNCH("bn_apply_pool");
   return RVIT_OK;
 }
 

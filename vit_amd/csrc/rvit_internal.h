@@ -143,6 +143,9 @@ int rvit_bn_stats_impl(const void* y, long M, int C, float* sums, hipStream_t st
 int rvit_bn_apply_impl(const void* y, const float* sums, const float* gamma, const float* beta, const void* res,
                        void* z, long M, int C, float eps, int relu, float momentum, float* running_mean,
                        float* running_var, void* relu_mask, hipStream_t st);
+int rvit_bn_apply_pool_impl(const void* y, const float* sums, const float* gamma, const float* beta, void* pooled,
+                            void* argmax, void* relu_mask, int B, int H, int W, int C, float eps, float momentum,
+                            float* running_mean, float* running_var, hipStream_t st);
 int rvit_bn_bwd_reduce_impl(const void* dz, const void* z, const void* y, const float* fsums, long M, int C, float eps,
                             int relu, float* bsums, hipStream_t st);
 int rvit_bn_bwd_apply_impl(const void* dz, const void* z, const void* y, const float* fsums, const float* bsums,

@@ -606,6 +606,30 @@ def bn_apply(y: torch.Tensor, sums: torch.Tensor, gamma: torch.Tensor, beta: tor
     return z
 
 
+def bn_apply_pool(y: torch.Tensor, sums: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, pooled: torch.Tensor,
+                  argmax: torch.Tensor, relu_mask: torch.Tensor, *, eps: float, momentum: float = 0.1,
+                  running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """BatchNorm (batch statistics in `sums`) + ReLU + MaxPool2d(3, 2, 1) of y [B,H,W,C] in one pass: pooled and
+    argmax [B,Ho,Wo,C], relu_mask uint8 [B*H*W*C/8]; the normalised map is not materialised."""
+    _need_cuda(y, sums, gamma, beta, pooled, argmax, relu_mask, running_mean, running_var)
+    if y.dim() != 4 or y.dtype != BF16 or not y.is_contiguous():
+        raise ValueError("bn_apply_pool: y must be a contiguous bf16 [B,H,W,C] map")
+    B, H, W, C = y.shape
+    shape = (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C)
+    if tuple(pooled.shape) != shape or pooled.dtype != BF16 or not pooled.is_contiguous() \
+            or tuple(argmax.shape) != shape or argmax.dtype != torch.uint8 or not argmax.is_contiguous():
+        raise ValueError(f"bn_apply_pool: pooled (bf16) and argmax (uint8) must be contiguous {shape}")
+    _check_relu_mask(relu_mask, B * H * W, C, True)
+    for v, n in ((sums, 2 * C), (gamma, C), (beta, C), (running_mean, C), (running_var, C)):
+        _vec_f32(v, n, "bn_apply_pool: vector")
+    with _Span("bn_apply_pool", 0, _nbytes(y, pooled, argmax, relu_mask)):
+        check(_lib.load().rvit_bn_apply_pool(y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             pooled.data_ptr(), argmax.data_ptr(), relu_mask.data_ptr(), B, H, W, C,
+                                             eps, momentum, _ptr(running_mean), _ptr(running_var), _stream()),
+              "rvit_bn_apply_pool")
+    return pooled
+
+
 def _check_relu_mask(mask, M, C, relu):
     if mask is None:
         return

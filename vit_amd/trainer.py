@@ -307,7 +307,6 @@ class TrainEngine:
         if m.cnn_backbone is not None:
             b["img"] = torch.zeros(B, 230, 232, 4, **z)
             b["c1_y"] = torch.empty(B, 112, 112, 64, **z)
-            b["c1_z"] = torch.empty(B, 112, 112, 64, **z)
             # sign bits of the ReLU outputs (one byte per 8 channels): what the BatchNorm backward reads instead of z
             b["c1_m"] = torch.empty(B * 112 * 112 * 8, dtype=torch.uint8, device=dev)
             b["pool"] = torch.empty(B, 56, 56, 64, **z)
@@ -383,10 +382,15 @@ class TrainEngine:
         b["fsums"].zero_()
         off = 0
         fs = b["fsums"]
-        self._conv_bn(b["img"], P["conv1_w"], b["c1_y"], b["c1_z"], cb.bn1, fs[off:off + 128], kh=7, kw=1, stride=2,
-                      pad=0, relu=True, seg_len=32, mask=b["c1_m"])
+        # stem entry: conv 7x7/2, then BatchNorm + ReLU + max-pool in one pass (the normalised 112x112 map is not
+        # written: the backward pass needs only its sign bits and the argmax taps)
+        ops.conv2d(b["img"], P["conv1_w"], b["c1_y"], kh=7, kw=1, stride=2, pad=0, seg_len=32)
+        ops.bn_stats(b["c1_y"], fs[off:off + 128])
+        ops.bn_apply_pool(b["c1_y"], fs[off:off + 128], cb.bn1.weight.detach(), cb.bn1.bias.detach(), b["pool"],
+                          b["pool_arg"], b["c1_m"], eps=cb.bn1.eps, momentum=cb.bn1.momentum,
+                          running_mean=cb.bn1.running_mean, running_var=cb.bn1.running_var)
+        cb.bn1.num_batches_tracked += 1
         off += 128
-        ops.maxpool3x3s2(b["c1_z"], b["pool"], b["pool_arg"])
         cur = b["pool"]
         for blk, pk, d in zip(cb.blocks(), P["blocks"], b["blocks"]):
             s, co = pk["stride"], pk["cout"]
@@ -521,9 +525,9 @@ class TrainEngine:
             # layout order inside a block is the reverse of module order: conv1.weight closes the block
             self._maybe_reduce(flat, pref + "conv1.weight")
         # max-pool and the 7x7 stem conv (its input is the image: no dgrad)
-        dc1 = self._scratch(b, ("dc1",), b["c1_z"])
+        dc1 = self._scratch(b, ("dc1",), b["c1_y"])
         ops.maxpool3x3s2_bwd(dz, b["pool_arg"], dc1)
-        dyc = self._scratch(b, ("dyc",), b["c1_z"])
+        dyc = self._scratch(b, ("dyc",), b["c1_y"])
         ops.bn_bwd(dc1, None, b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(), dyc,
                    self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"), eps=cb.bn1.eps,
                    relu=True, relu_mask=b["c1_m"])
