@@ -68,7 +68,7 @@ class Engine:
 
     # ---- weight packing ----------------------------------------------------------------------
     def _key(self):
-        ps = list(self.m.parameters()) + list(self.m.buffers())
+        ps = self.m._live_tensors()
         return (tuple(p._version for p in ps), ps[0].data_ptr(), ps[0].device, self.m.training, self.precision)
 
     @torch.no_grad()

@@ -213,6 +213,47 @@ class CNNViTHybrid(nn.Module):
             object.__setattr__(self, "_train_engine", TrainEngine(self))
         return self._train_engine
 
+    # ---- cached parameter / buffer lists ----------------------------------------------------------------
+    # Module.parameters() walks the module tree (~100 us for this model); the engines need the lists on every
+    # forward (version keys, autograd inputs).  The walk is done once; every later call only re-checks that each
+    # slot of each module still holds the same tensor object (a replaced Parameter rebuilds the lists).  Modules
+    # added after the first forward are not noticed: call `_forget_tensor_lists()` after such surgery.
+    def _tensor_slots(self):
+        cache = self.__dict__.get("_slots_cache")
+        if cache is not None:
+            for d, n, t in cache[0]:
+                if d.get(n) is not t:
+                    cache = None
+                    break
+        if cache is None:
+            slots, seen = [], set()
+            mods = list(self.modules())
+            for mod in mods:
+                for n, t in mod._parameters.items():
+                    if t is not None and id(t) not in seen:
+                        seen.add(id(t))
+                        slots.append((mod._parameters, n, t))
+            nparam = len(slots)
+            for mod in mods:
+                for n, t in mod._buffers.items():
+                    if t is not None and id(t) not in seen:
+                        seen.add(id(t))
+                        slots.append((mod._buffers, n, t))
+            cache = (slots, [t for _, _, t in slots[:nparam]], [t for _, _, t in slots])
+            object.__setattr__(self, "_slots_cache", cache)
+        return cache
+
+    def _live_params(self):
+        """== list(self.parameters()), cached."""
+        return self._tensor_slots()[1]
+
+    def _live_tensors(self):
+        """== list(self.parameters()) + list(self.buffers()), cached."""
+        return self._tensor_slots()[2]
+
+    def _forget_tensor_lists(self) -> None:
+        self.__dict__.pop("_slots_cache", None)
+
     def invalidate_packs(self) -> None:
         """Drop the inference engine's packed weight copies.  Called automatically on every train-mode forward, on
         train()/eval() switches and (through parameter version counters) after load_state_dict; call it by hand
@@ -250,7 +291,7 @@ class CNNViTHybrid(nn.Module):
             self.invalidate_packs()
             from .trainer import HybridFunction
             if torch.is_grad_enabled():
-                return HybridFunction.apply(x, self.train_engine, features_only, *self.parameters())
+                return HybridFunction.apply(x, self.train_engine, features_only, *self._live_params())
             return self.train_engine.forward(x, features_only)
         return self.engine.run(x, features_only)
 

@@ -54,7 +54,14 @@ def _nbytes(*ts) -> int:
     return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream
+    object through several Python layers (~8 us, ~400 times per training step); the raw getter is one C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

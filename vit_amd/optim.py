@@ -71,7 +71,7 @@ class FusedAdamW(torch.optim.Optimizer):
             raise RuntimeError("FusedAdamW: frozen parameters (requires_grad=False) are not supported; "
                                "use a torch optimiser while part of the model is frozen")
         flat_g = getattr(self._eng, "last_flat", None)
-        first = next(iter(self.model.parameters()))
+        first = self._probe[0][0]
         if flat_g is None or first.grad is None:
             raise RuntimeError("FusedAdamW.step: no gradients; call loss.backward() on a train()-mode forward first")
         # the gradients must be the views the librvit backward handed to autograd (not accumulated copies):

@@ -231,7 +231,7 @@ class TrainEngine:
 
     # ---- packing ---------------------------------------------------------------------------------
     def _key(self):
-        ps = list(self.m.parameters())
+        ps = self.m._live_params()
         return (tuple(p._version for p in ps), ps[0].data_ptr())
 
     @torch.no_grad()
