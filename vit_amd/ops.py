@@ -51,6 +51,8 @@ class _Span:
 
 
 def _nbytes(*ts) -> int:
+    if _PROF is None:   # only the profiler reads it
+        return 0
     return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
 
