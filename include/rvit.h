@@ -179,6 +179,12 @@ int rvit_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gam
                        int y_dtype, int64_t ldy, float* mean, float* rstd, int64_t rows, int E, float eps,
                        void* stream);
 
+/* LayerNorm whose output is MXFP8, the operand format of rvit_gemm_mxfp8 (inference, BASELINE configs[4]): the
+ * bytes equal rvit_layernorm_fwd (bf16 output) followed by rvit_quantize_mxfp8, in one pass.  E % 128 == 0;
+ * q: e4m3 [rows, ldq]; scales: E8M0, tiled as for rvit_quantize_mxfp8. */
+int rvit_layernorm_mxfp8_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                             uint8_t* q, int64_t ldq, uint8_t* scales, int64_t rows, int E, float eps, void* stream);
+
 /* LayerNorm backward fused with the residual-gradient accumulation of the pre-LN block
  * (x + f(LN(x)), torch transformer.py:947-950):  dx (+)= LN'(dy); dgamma += ..., dbeta += ...
  *   dy: bf16 [rows,lddy]; x: f32 [rows,ldx] (the LN input); mean/rstd from the forward;

@@ -202,3 +202,26 @@ def test_model_mxfp8_inference_matches_emulation(dev, name, cfg, B):
             assert int(mx[i].argmax()) == int(fp32[i].argmax())
     with pytest.raises(ValueError):
         m.set_inference_precision("int4")
+
+
+@pytest.mark.parametrize("rows,E,dtype", [(197 * 3, 1024, torch.float32), (50, 128, torch.float32), (333, 768, torch.bfloat16),
+                                          (17, 2048, torch.float32)])
+def test_layernorm_mx_equals_layernorm_then_quantize(dev, rows, E, dtype):
+    """LayerNorm with MX-fp8 output (csrc/norm.hip) gives exactly the bytes of layernorm (bf16) -> quantize_mx: values,
+    and every scale byte the two-kernel path writes (ragged row counts: the tiled scale matrix has unwritten padding)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(rows + E)
+    x = (torch.randn(rows, E, generator=g) * 2.0 + 0.3).to(dtype).to(dev)
+    gamma, beta = (torch.rand(E, generator=g) + 0.5).to(dev), (torch.randn(E, generator=g) * 0.2).to(dev)
+    ln = torch.empty(rows, E, dtype=torch.bfloat16, device=dev)
+    ops.layernorm(x, gamma, beta, ln, 1e-6)
+    q_ref = torch.zeros(rows, E, dtype=torch.uint8, device=dev)
+    s_ref = torch.zeros(ops.mx_scale_shape(rows, E), dtype=torch.uint8, device=dev)
+    ops.quantize_mx(ln, q_ref, s_ref)
+    q = torch.full_like(q_ref, 0x55)
+    s = torch.zeros_like(s_ref)
+    ops.layernorm_mx(x, gamma, beta, q, s, 1e-6)
+    assert torch.equal(q, q_ref)
+    assert torch.equal(s, s_ref)
+    with pytest.raises(ValueError):
+        ops.layernorm_mx(x[:, :96], gamma[:96], beta[:96], q[:, :96], s, 1e-6)

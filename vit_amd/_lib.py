@@ -48,6 +48,7 @@ SIGNATURES = {
     "rvit_embed_cls": ([P, P, P, I, I, I, F, U64, P], c_int),
     "rvit_dropout_apply": ([P, P, I, L, I, L, L, F, U64, P], c_int),
     "rvit_dropout_mask": ([P, L, F, U64, P], c_int),
+    "rvit_layernorm_mxfp8_fwd": ([P, I, L, P, P, P, L, P, L, I, F, P], c_int),
     "rvit_layernorm_fwd": ([P, I, L, P, P, P, I, L, P, P, L, I, F, P], c_int),
     "rvit_layernorm_bwd": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P], c_int),
     "rvit_attn_fwd": ([P, P, P, I, I, I, L, L, F, F, U64, P], c_int),

@@ -209,6 +209,13 @@ int rvit_dropout_mask(uint8_t* out, int64_t n, float p, uint64_t seed, void* str
   return rvit_dropout_mask_impl(out, n, p, seed, (hipStream_t)stream);
 }
 
+int rvit_layernorm_mxfp8_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                             uint8_t* q, int64_t ldq, uint8_t* scales, int64_t rows, int E, float eps, void* stream) {
+  RVIT_CHECK_ARG(x_dtype == RVIT_F32 || x_dtype == RVIT_BF16, "layernorm_mx: x must be f32 or bf16");
+  return rvit_layernorm_mx_fwd_impl(x, x_dtype == RVIT_F32, ldx, gamma, beta, q, ldq, scales, rows, E, eps,
+                                    (hipStream_t)stream);
+}
+
 int rvit_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y,
                        int y_dtype, int64_t ldy, float* mean, float* rstd, int64_t rows, int E, float eps,
                        void* stream) {

@@ -24,6 +24,7 @@
 // GEMM consumes it without a separate quantisation pass.
 #include "common.h"
 #include "rvit_internal.h"
+#include "mx_common.h"
 
 namespace {
 
@@ -36,30 +37,6 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void glds16(const void* src, char* lds_dst_wave_base) {
   __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_wave_base, 16, 0, 0);
 }
-
-// E8M0 scale of an MX block with absolute maximum `amax`: 2^(floor(log2 amax) - 8) (8 = emax of e4m3),
-// biased by 127; amax == 0 -> scale 2^-127 (all elements quantise to 0).
-__device__ __forceinline__ int mx_scale_e8m0(float amax) {
-  const int e = (int)((__float_as_uint(amax) >> 23) & 0xff);  // biased exponent of amax (0 for 0 / denormals)
-  int s = e - 8;
-  return s < 0 ? 0 : s;
-}
-// 4 floats -> 4 packed e4m3 bytes after multiplying by 2^-scale (exact) and saturating to +-448
-__device__ __forceinline__ uint32_t mx_pack4(float a, float b, float c, float d, float inv_scale) {
-  a = fminf(fmaxf(a * inv_scale, -448.f), 448.f);
-  b = fminf(fmaxf(b * inv_scale, -448.f), 448.f);
-  c = fminf(fmaxf(c * inv_scale, -448.f), 448.f);
-  d = fminf(fmaxf(d * inv_scale, -448.f), 448.f);
-  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  return (uint32_t)w;
-}
-// byte offset of the scale of (row r, element k) in the tiled scale matrix of a [rows, K] operand
-__device__ __forceinline__ long mx_scale_offset(long r, int k, int K) {
-  const int kt = k >> 7, nk4 = ((K >> 7) + 3) >> 2;
-  return ((((r >> 4) * nk4 + (kt >> 2)) * 64 + (r & 15) * 4 + ((k >> 5) & 3)) << 2) + (kt & 3);
-}
-__device__ __forceinline__ float mx_inv_scale(int s) { return __uint_as_float((uint32_t)(254 - s) << 23); }  // 2^(127-s)
 
 constexpr int MX_BM = 256, MX_BN = 64, MX_WAVES = 8, MX_WM = 32;
 constexpr int MX_TILE_BYTES = (MX_BM + MX_BN) * 128;  // 40 KB per stage

@@ -118,6 +118,8 @@ int rvit_conv3x3_wgrad_direct(const WgradArgs& a, hipStream_t st);
 int rvit_layernorm_fwd_impl(const void* x, int x_f32, long ldx, const float* gamma, const float* beta, void* y,
                             int y_f32, long ldy, float* mean, float* rstd, long rows, int E, float eps,
                             hipStream_t st);
+int rvit_layernorm_mx_fwd_impl(const void* x, int x_f32, long ldx, const float* gamma, const float* beta, uint8_t* q,
+                               long ldq, uint8_t* sc, long rows, int E, float eps, hipStream_t st);
 int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                             const float* gamma, float* dxs, long lddx, int accumulate, void* dx_bf16, long lddb,
                             float* dgamma, float* dbeta, long rows, int E, hipStream_t st);

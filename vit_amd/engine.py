@@ -208,14 +208,13 @@ class Engine:
         x2 = b["x"].view(B * S, E)
         if self.precision == "mxfp8":
             aq, as_ = b["a_q"], b["a_s"]
-            ops.layernorm(x2, L["ln1_w"], L["ln1_b"], b["ln"], L["eps1"])
-            ops.quantize_mx(b["ln"], aq, as_)
+            # LayerNorm emits its result directly as MX-fp8 (same bytes as layernorm -> quantize_mx, one pass)
+            ops.layernorm_mx(x2, L["ln1_w"], L["ln1_b"], aq, as_, L["eps1"])
             ops.gemm_mx(aq, as_, L["qkv_w_q"], L["qkv_w_s"], b["qkv"], bias=L["qkv_b"])
             ops.attention(b["qkv"], b["att"], B, S, H)
             ops.quantize_mx(b["att"], aq, as_)
             ops.gemm_mx(aq, as_, L["out_w_q"], L["out_w_s"], x2, bias=L["out_b"], residual=x2)
-            ops.layernorm(x2, L["ln2_w"], L["ln2_b"], b["ln"], L["eps2"])
-            ops.quantize_mx(b["ln"], aq, as_)
+            ops.layernorm_mx(x2, L["ln2_w"], L["ln2_b"], aq, as_, L["eps2"])
             # linear1's epilogue emits the GELU output directly as MX-fp8 (no bf16 copy, no quantisation pass)
             ops.gemm_mx(aq, as_, L["fc1_w_q"], L["fc1_w_s"], None, bias=L["fc1_b"], act="gelu", out_q=b["hid_q"],
                         out_s=b["hid_s"])

@@ -398,6 +398,26 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
     return out
 
 
+def layernorm_mx(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, q: torch.Tensor, scales: torch.Tensor,
+                 eps: float = 1e-5):
+    """Row LayerNorm with MXFP8 output (== layernorm to bf16, then quantize_mx, in one pass): x [rows,E] bf16/f32,
+    q uint8 [rows,E] e4m3 bytes, scales uint8 tiled (ops.mx_scale_shape(rows, E)); E % 128 == 0."""
+    _need_cuda(x, gamma, beta, q, scales)
+    rows, E, ldx = _rows2d(x, "layernorm_mx x")
+    if E % 128 or x.dtype not in (BF16, torch.float32):
+        raise ValueError("layernorm_mx: E must be a multiple of 128, x bf16 or f32")
+    if q.shape != (rows, E) or q.dtype != torch.uint8 or q.stride(1) != 1 or tuple(scales.shape) != mx_scale_shape(rows, E) \
+            or scales.dtype != torch.uint8 or not scales.is_contiguous():
+        raise ValueError("layernorm_mx: q [rows,E] / tiled scales (ops.mx_scale_shape) must be uint8")
+    _vec_f32(gamma, E, "layernorm_mx: gamma")
+    _vec_f32(beta, E, "layernorm_mx: beta")
+    with _Span("layernorm_mx_fwd", 0, rows * E * (x.element_size() + 1) + 8 * E):
+        check(_lib.load().rvit_layernorm_mxfp8_fwd(x.data_ptr(), _dt(x), ldx, gamma.data_ptr(), beta.data_ptr(),
+                                                   q.data_ptr(), q.stride(0), scales.data_ptr(), rows, E, eps, _stream()),
+              "rvit_layernorm_mxfp8_fwd")
+    return q, scales
+
+
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, lse: Optional[torch.Tensor] = None,
               scale: Optional[float] = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
     """qkv bf16 [B*S, 3*H*64] (q|k|v), out bf16 [B*S, H*64]; softmax(q k^T scale) v per head."""
