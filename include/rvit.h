@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 5
+#define RVIT_ABI_VERSION 6
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
