@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 6
+#define RVIT_ABI_VERSION 7
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -115,6 +115,19 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
 int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int KH, int KW,
                            int stride, int pad, int Hx, int Wx, int Cin, const void* residual, int tile,
                            void* stream);
+
+/* Input gradient of a 3x3 / stride 2 / pad 1 conv (the first conv of resnet layers 2-4, train_vit.py:87 through
+ * autograd), decomposed by output parity into four dense stride-1 convs over dY (9 taps of work instead of 36):
+ * dy [B, Hy, Wy, Cout] -> dx [B, 2*Hy, 2*Wy, Cin] (+ residual of the same shape).  w_s2: bf16 [Cin, 9*Cout], block p
+ * of the K axis = transposed tap RVIT_S2_TAP_ORDER[p] = {4, 5, 3, 7, 1, 8, 6, 2, 0}[p] of the [Cout, 3, 3, Cin]
+ * weight (tap = 3*kh + kw). */
+int rvit_conv2d_dgrad_s2_bf16(const void* dy, const void* w_s2, void* dx, int B, int Hy, int Wy, int Cout, int Cin,
+                              const void* residual, void* stream);
+
+/* Input gradient of the 1x1 / stride 2 downsample conv, accumulated: dx[b, 2i, 2j, :] += dy[b, i, j, :] . w_t^T
+ * (w_t bf16 [Cin, Cout]); the other three quarters of dx are left as they are. */
+int rvit_conv1x1_dgrad_s2_acc_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int Cin,
+                                   void* stream);
 
 /* Patch-embedding convolution straight into the token stream (pure-ViT `patch16` layout; the
  * same flatten/transpose/cls-offset/pos_embed epilogue as the 1x1 case, train_vit.py:149-159):

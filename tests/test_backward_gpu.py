@@ -356,3 +356,38 @@ def test_bn_apply_pool_fused(dev, B, H, W, C):
                                                    True, 0.1, 1e-5))
     pr = torch.nn.functional.max_pool2d(zr, 3, 2, 1).permute(0, 2, 3, 1)
     assert (p.float().cpu() - pr).abs().max().item() <= 2.0 ** -7 * max(1.0, pr.abs().max().item())
+
+
+@pytest.mark.parametrize("B,Hy,Wy,cin,cout", [(2, 28, 28, 64, 128), (3, 7, 7, 256, 512), (1, 5, 9, 64, 64)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv_dgrad_stride2_by_parity(dev, B, Hy, Wy, cin, cout, with_res):
+    """Input gradient of a 3x3 / stride 2 / pad 1 conv decomposed by output parity (four dense stride-1 convs over dY)
+    and the accumulating 1x1 / stride 2 form, against torch autograd and against the generic transposed gather."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(B + Hy + cin)
+    w = _bf(torch.randn(cout, 3, 3, cin, generator=g) / math.sqrt(9 * cin))            # [Cout, kh, kw, Cin]
+    dy = _bf(torch.randn(B, Hy, Wy, cout, generator=g))
+    res = _bf(torch.randn(B, 2 * Hy, 2 * Wy, cin, generator=g)) if with_res else None
+    xr = torch.zeros(B, cin, 2 * Hy, 2 * Wy, requires_grad=True)
+    F.conv2d(xr, w.float().permute(0, 3, 1, 2), None, 2, 1).backward(dy.float().permute(0, 3, 1, 2))
+    want = xr.grad.permute(0, 2, 3, 1) + (res.float() if with_res else 0)
+    taps = w.permute(3, 1, 2, 0).reshape(cin, 9, cout)                                  # [Cin, tap, Cout]
+    w_s2 = taps[:, list(ops.S2_TAP_ORDER), :].reshape(cin, 9 * cout).contiguous().to(dev)
+    dx = torch.full((B, 2 * Hy, 2 * Wy, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.conv2d_dgrad_s2(dy.to(dev), w_s2, dx, residual=None if res is None else res.to(dev))
+    _close(dx, want, 1.0 / 128, 2e-2, "stride-2 dgrad by parity")
+    dx_old = torch.empty_like(dx)
+    ops.conv2d_dgrad(dy.to(dev), taps.reshape(cin, 9 * cout).contiguous().to(dev), dx_old, kh=3, kw=3, stride=2, pad=1,
+                     residual=None if res is None else res.to(dev))
+    assert (dx.float() - dx_old.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, dx_old.float().abs().max().item())
+    # 1x1 / stride 2, accumulated into dx: only the (even, even) pixels change
+    w1 = _bf(torch.randn(cout, cin, generator=g) / math.sqrt(cin))                      # [Cout, Cin]
+    before = dx.clone()
+    ops.conv1x1_dgrad_s2_acc(dy.to(dev), w1.t().contiguous().to(dev), dx)
+    add = dy.float() @ w1.float()                                                       # [B,Hy,Wy,Cin]
+    want2 = before.float().cpu().clone()
+    want2[:, ::2, ::2, :] += add
+    _close(dx, want2, 1.0 / 128, 2e-2, "1x1 stride-2 dgrad, accumulated")
+    mask = torch.ones(2 * Hy, 2 * Wy, dtype=torch.bool)
+    mask[::2, ::2] = False
+    assert torch.equal(dx[:, mask.to(dev)], before[:, mask.to(dev)])

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -39,6 +39,8 @@ SIGNATURES = {
     "rvit_quantize_mxfp8": ([P, I, L, P, L, P, L, I, P], c_int),
     "rvit_conv2d_fwd_bf16": ([P, P, P] + [I] * 12 + [P, P, P, I, I, P], c_int),
     "rvit_conv2d_dgrad_bf16": ([P, P, P] + [I] * 11 + [P, I, P], c_int),
+    "rvit_conv2d_dgrad_s2_bf16": ([P, P, P, I, I, I, I, I, P, P], c_int),
+    "rvit_conv1x1_dgrad_s2_acc_bf16": ([P, P, P, I, I, I, I, I, P], c_int),
     "rvit_conv2d_tokens_fwd": ([P, P, P] + [I] * 12 + [P, P, F, U64, I, P], c_int),
     "rvit_wgrad_bf16": ([P, L, I, I, P, L, I, I, P, L, L, I, I, I, I, P], c_int),
     "rvit_conv2d_wgrad_bf16": ([P, P, P] + [I] * 12 + [I, P], c_int),

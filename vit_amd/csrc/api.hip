@@ -130,6 +130,55 @@ int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_conv2d_dgrad_s2_bf16(const void* dy, const void* w_s2, void* dx, int B, int Hy, int Wy, int Cout, int Cin,
+                              const void* residual, void* stream) {
+  // Input gradient of a 3x3 / stride 2 / pad 1 conv by output parity.  dX pixel (2i+ph, 2j+pw) only receives the taps
+  // with kh = 1 (ph = 0) or kh in {2, 0} (ph = 1), likewise kw: four dense stride-1 convs over dY with 1x1, 1x2,
+  // 2x1 and 2x2 taps (9 taps in all instead of 4 x 9 with three quarters of them reading zeros).  Tap (kh', kw')
+  // of class (ph, pw) reads dY[i + kh', j + kw'] (out of range = 0, the forward gather's bounds check); each class
+  // writes its own lattice of dX: row pitch 2*Cin with the row remap (m / Wy) * 2*Wy + m % Wy + Wy.
+  RVIT_CHECK_ARG(dy && w_s2 && dx && B > 0 && Hy > 0 && Wy > 0, "conv dgrad s2: bad geometry");
+  RVIT_CHECK_ARG((Cout & 63) == 0 && (Cin & 7) == 0, "conv dgrad s2: Cout=%d must be a multiple of 64, Cin=%d of 8", Cout, Cin);
+  RVIT_CHECK_ARG((long)B * Hy * Wy * 4 < 0x7fffffffL, "conv dgrad s2: too many pixels");
+  RVIT_CHECK_ARG(aligned_to(dx, 16) && (!residual || aligned_to(residual, 16)), "conv dgrad s2: alignment");
+  static const int k_off[4] = {0, 1, 3, 5};   // first K block (in taps) of class 2*ph + pw in w_s2
+  const int Wx = 2 * Wy;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    GemmArgs a{};
+    conv_geometry(a, dy, (const bf16*)w_s2 + (long)k_off[cls] * Cout, B, Hy, Wy, Cout, Cout, 1 + ph, 1 + pw, 1, 0, Hy, Wy,
+                  Cin);
+    a.ldb = 9L * Cout;
+    const long base = ((long)ph * Wx + pw - Wx) * Cin;   // + remapped row * 2*Cin = pixel (2i+ph, 2j+pw)
+    a.C = (bf16*)dx + base; a.ldc = 2L * Cin; a.c_f32 = 0;
+    a.R = residual ? (const bf16*)residual + base : nullptr; a.ldr = 2L * Cin; a.r_f32 = 0;
+    a.row_group = Wy; a.row_extra = Wy;
+    a.tile = 0;
+    a.vec = 1;
+    const int rc = rvit_gemm_dispatch(a, (hipStream_t)stream);
+    if (rc != RVIT_OK) return rc;
+  }
+  return RVIT_OK;
+}
+
+int rvit_conv1x1_dgrad_s2_acc_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int Cin,
+                                   void* stream) {
+  // Input gradient of a 1x1 / stride 2 conv (the resnet downsample branch), ADDED to dx: only the (even, even) pixels
+  // of dx receive anything, dx[b, 2i, 2j, :] += dy[b, i, j, :] . w_t^T - a plain GEMM whose output rows are that lattice.
+  RVIT_CHECK_ARG(dy && w_t && dx && B > 0 && Hy > 0 && Wy > 0, "conv1x1 dgrad s2: bad geometry");
+  RVIT_CHECK_ARG((Cout & 7) == 0 && (Cin & 7) == 0 && aligned_to(dx, 16), "conv1x1 dgrad s2: channels must be multiples of 8");
+  GemmArgs a{};
+  a.A = (const bf16*)dy; a.lda = Cout;
+  a.B = (const bf16*)w_t; a.ldb = Cout;
+  a.M = (long)B * Hy * Wy; a.N = Cin; a.K = Cout;
+  const long base = -2L * Wy * Cin;
+  a.C = (bf16*)dx + base; a.ldc = 2L * Cin; a.c_f32 = 0;
+  a.R = (const bf16*)dx + base; a.ldr = 2L * Cin; a.r_f32 = 0;
+  a.row_group = Wy; a.row_extra = Wy;
+  a.vec = 1;
+  return rvit_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* bias,
                            const float* pos_embed, float drop_p, uint64_t drop_seed, int tile, void* stream) {

@@ -493,6 +493,43 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
     return dx
 
 
+S2_TAP_ORDER = (4, 5, 3, 7, 1, 8, 6, 2, 0)   # K-block order of the w_s2 pack (include/rvit.h)
+
+
+def conv2d_dgrad_s2(dy: torch.Tensor, w_s2: torch.Tensor, dx: torch.Tensor, *,
+                    residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx = conv_transpose(dy, w) (+ residual) for a 3x3 / stride 2 / pad 1 conv, by output parity (four dense
+    stride-1 convs, no zero taps); dy bf16 [B,Hy,Wy,Cout], dx bf16 [B,2Hy,2Wy,Cin], w_s2 bf16 [Cin, 9*Cout] with
+    the taps in S2_TAP_ORDER."""
+    _need_cuda(dy, w_s2, dx, residual)
+    B, Hy, Wy, Cout = dy.shape
+    Bx, Hx, Wx, Cin = dx.shape
+    if Bx != B or Hx != 2 * Hy or Wx != 2 * Wy or w_s2.shape != (Cin, 9 * Cout) or dy.dtype != BF16 or dx.dtype != BF16 \
+            or w_s2.dtype != BF16 or not (dy.is_contiguous() and dx.is_contiguous() and w_s2.is_contiguous()):
+        raise ValueError("conv2d_dgrad_s2: bad operands")
+    if residual is not None and (residual.shape != dx.shape or residual.dtype != BF16 or not residual.is_contiguous()):
+        raise ValueError("conv2d_dgrad_s2: residual must match dx")
+    with _Span("conv2d_dgrad", 2 * B * Hy * Wy * Cout * 9 * Cin, _nbytes(dy, w_s2, dx, residual)):
+        check(_lib.load().rvit_conv2d_dgrad_s2_bf16(dy.data_ptr(), w_s2.data_ptr(), dx.data_ptr(), B, Hy, Wy, Cout, Cin,
+                                                    _ptr(residual), _stream()), "rvit_conv2d_dgrad_s2_bf16")
+    return dx
+
+
+def conv1x1_dgrad_s2_acc(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor) -> torch.Tensor:
+    """dx[:, ::2, ::2, :] += dy @ w_t.T : input gradient of a 1x1 / stride 2 conv added to dx (the other pixels of dx
+    get nothing from such a conv); dy bf16 [B,Hy,Wy,Cout], w_t bf16 [Cin,Cout], dx bf16 [B,2Hy,2Wy,Cin]."""
+    _need_cuda(dy, w_t, dx)
+    B, Hy, Wy, Cout = dy.shape
+    Bx, Hx, Wx, Cin = dx.shape
+    if Bx != B or Hx != 2 * Hy or Wx != 2 * Wy or w_t.shape != (Cin, Cout) or dy.dtype != BF16 or dx.dtype != BF16 \
+            or w_t.dtype != BF16 or not (dy.is_contiguous() and dx.is_contiguous() and w_t.is_contiguous()):
+        raise ValueError("conv1x1_dgrad_s2_acc: bad operands")
+    with _Span("conv2d_dgrad", 2 * B * Hy * Wy * Cout * Cin, _nbytes(dy, w_t) + B * Hy * Wy * Cin * 4):
+        check(_lib.load().rvit_conv1x1_dgrad_s2_acc_bf16(dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), B, Hy, Wy, Cout,
+                                                         Cin, _stream()), "rvit_conv1x1_dgrad_s2_acc_bf16")
+    return dx
+
+
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
                   dx: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, *, accumulate: bool,
                   dx_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -37,8 +37,11 @@ def _conv_fwd_pack(w: torch.Tensor) -> torch.Tensor:   # [Cout,Cin,kh,kw] -> [Co
     return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(BF16).contiguous()
 
 
-def _conv_bwd_pack(w: torch.Tensor) -> torch.Tensor:   # [Cout,Cin,kh,kw] -> [Cin, kh*kw*Cout]
-    return w.detach().permute(1, 2, 3, 0).reshape(w.shape[1], -1).to(BF16).contiguous()
+def _conv_bwd_pack(w: torch.Tensor, tap_order=None) -> torch.Tensor:   # [Cout,Cin,kh,kw] -> [Cin, kh*kw*Cout]
+    t = w.detach().permute(1, 2, 3, 0).reshape(w.shape[1], w.shape[2] * w.shape[3], w.shape[0])   # [Cin, tap, Cout]
+    if tap_order is not None:   # K block p holds tap tap_order[p] (stride-2 input gradient by parity, ops.S2_TAP_ORDER)
+        t = t[:, list(tap_order), :]
+    return t.reshape(w.shape[1], -1).to(BF16).contiguous()
 
 
 def _px4_pack(w: torch.Tensor, kw_pad: int) -> torch.Tensor:
@@ -61,7 +64,7 @@ class _TorchPacker:
     def b(self, n): return _b(self._2d(n))
     def t(self, n): return _t(self._2d(n))
     def conv_fwd(self, n): return _conv_fwd_pack(self.p[n])
-    def conv_bwd(self, n): return _conv_bwd_pack(self.p[n])
+    def conv_bwd(self, n, tap_order=None): return _conv_bwd_pack(self.p[n], tap_order)
     def px4(self, n, kw_pad): return _px4_pack(self.p[n], kw_pad)
 
     def t_padded(self, n, mult):
@@ -122,13 +125,14 @@ class WeightMirror:
         self._entries.append((off, d, N, K, K, N))
         return ("wt", d, numel, (K, N))
 
-    def conv_bwd(self, n):
+    def conv_bwd(self, n, tap_order=None):
         off, numel, shape = self._seg(n)
         co, ci, kh, kw = shape
         T = kh * kw
         d = self._alloc(numel)
-        for tap in range(T):   # dst[ci, tap, co] = src[co, tap, ci]
-            self._entries.append((off + tap * ci, d + tap * co, co, ci, T * ci, T * co))
+        order = range(T) if tap_order is None else tap_order
+        for pos, tap in enumerate(order):   # dst[ci, pos, co] = src[co, tap, ci]
+            self._entries.append((off + tap * ci, d + pos * co, co, ci, T * ci, T * co))
         return ("wt", d, numel, (ci, T * co))
 
     def px4(self, n, kw_pad):
@@ -262,8 +266,11 @@ class TrainEngine:
             P["conv1_w"] = pk.px4("cnn_backbone.conv1.weight", 8)
             blocks = []
             for pref, blk in self._stem_blocks():
+                # a stride-2 conv1 gets its input-gradient pack in the parity order of rvit_conv2d_dgrad_s2_bf16
+                s2 = blk.conv1.stride == 2
                 d = {"stride": blk.conv1.stride, "cin": blk.conv1.cin, "cout": blk.conv1.cout,
-                     "c1_w": pk.conv_fwd(pref + "conv1.weight"), "c1_wt": pk.conv_bwd(pref + "conv1.weight"),
+                     "c1_w": pk.conv_fwd(pref + "conv1.weight"),
+                     "c1_wt": pk.conv_bwd(pref + "conv1.weight", ops.S2_TAP_ORDER if s2 else None),
                      "c2_w": pk.conv_fwd(pref + "conv2.weight"), "c2_wt": pk.conv_bwd(pref + "conv2.weight")}
                 if blk.downsample is not None:
                     d["ds_w"] = pk.conv_fwd(pref + "downsample.0.weight")
@@ -516,9 +523,14 @@ class TrainEngine:
                            eps=blk.downsample["1"].eps, relu=False)
                 ops.conv2d_wgrad(dyd, xin, self._g(flat, pref + "downsample.0.weight").view(co, ci), kh=1, kw=1,
                                  stride=s, pad=0)
-                tmp = self._scratch(b, ("dxt", ci, xin.shape[1]), xin)
-                ops.conv2d_dgrad(dyd, pk["ds_wt"], tmp, kh=1, kw=1, stride=s, pad=0)
-                ops.conv2d_dgrad(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=s, pad=1, residual=tmp)
+                if s == 2:
+                    # by output parity: no zero taps for the 3x3, and the 1x1 only touches the (even, even) pixels
+                    ops.conv2d_dgrad_s2(dy1, pk["c1_wt"], dxin)
+                    ops.conv1x1_dgrad_s2_acc(dyd, pk["ds_wt"], dxin)
+                else:
+                    tmp = self._scratch(b, ("dxt", ci, xin.shape[1]), xin)
+                    ops.conv2d_dgrad(dyd, pk["ds_wt"], tmp, kh=1, kw=1, stride=s, pad=0)
+                    ops.conv2d_dgrad(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=s, pad=1, residual=tmp)
             else:
                 ops.conv2d_dgrad(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=s, pad=1, residual=dzm)
             dz = dxin
