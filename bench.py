@@ -9,7 +9,7 @@ N>1 is launched by torch.distributed.run, one rank per GPU; rank 0 prints ONE JS
 
 A "step" is one forward pass of the hot path (image pack -> stem -> patch embed -> encoder ->
 head) over one batch already resident in HBM.  `roofline` is measured live with HIP events around
-every launch of the dominant kernel (the LDS-resident 3x3 conv, csrc/conv3x3.hip); `cpu_baseline` times the torch fp32
+every launch of the dominant kernel (the LDS-resident 3x3 conv of layers 2-4, csrc/conv3x3.hip); `cpu_baseline` times the torch fp32
 oracle (the reference's own torch.nn arithmetic) on this box's host cores on a bounded sample.
 """
 import argparse
@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: RCCL needs this before the HIP runtime starts (normally exported
+# by the environment already)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
