@@ -179,6 +179,30 @@ def test_streaming_classifier(dev):
     assert b["mode"] == "sequence" and b["fps"] > 0
 
 
+def test_streaming_classifier_device_preprocess(dev):
+    """device_preprocess=True: uint8 frames are resized / normalised on the GPU; the tensor the model sees equals the
+    host transform's bit for bit, so the predictions are the same."""
+    import numpy as np
+    from vit_amd.infer import preprocess
+    from vit_amd.sequence import StreamingClassifier
+    mine, _ = _pair(dev, seed=5)
+    classes = [f"c{i}" for i in range(11)]
+    host = StreamingClassifier(model=mine, classes=classes, config=CFG, smoothing_window=1)
+    gpu = StreamingClassifier(model=mine, classes=classes, config=CFG, smoothing_window=1, device_preprocess=True)
+    rng = np.random.default_rng(3)
+    frames = [(rng.random((201, 368, 3)) * 255).astype(np.uint8) for _ in range(5)]
+    from PIL import Image
+    want = preprocess(Image.fromarray(frames[0]))
+    got = gpu._preprocess(frames[0]).cpu()
+    assert torch.equal(want, got)
+    assert torch.equal(preprocess(frames[1][:, :, 0]), gpu._preprocess(np.ascontiguousarray(frames[1][:, :, 0])).cpu())  # luma
+    for fr in frames:
+        a, b = host.update(fr), gpu.update(fr)
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert a.prediction == b.prediction and abs(a.confidence - b.confidence) < 1e-6
+
+
 def test_sequence_checkpoint_round_trip(dev, tmp_path):
     """A checkpoint in the reference layout (train_vit.py:996-1019) with mode 'sequence' loads through
     vit_amd.infer.load_model and through StreamingClassifier(model_path) with the restricted unpickler."""

@@ -342,7 +342,11 @@ class StreamingClassifier:
     weights_only=True) or a ready (model, classes, config) triple."""
 
     def __init__(self, model_path=None, device: str = "auto", smoothing_window: int = 3, *, model=None, classes=None,
-                 config=None, confidence_threshold: float = 0.5):
+                 config=None, confidence_threshold: float = 0.5, device_preprocess: bool = False):
+        # device_preprocess: uint8 frames given as arrays are resized / normalised on the GPU (vit_amd.pipeline, the
+        # same arithmetic as the host transform, bit for bit) instead of by Pillow on the host
+        self.device_preprocess = bool(device_preprocess)
+        self._pre = {}
         self.device = torch.device("cuda" if device == "auto" else device)
         if self.device.type != "cuda":
             raise RuntimeError("StreamingClassifier runs on the GPU through librvit only")
@@ -374,6 +378,14 @@ class StreamingClassifier:
         if isinstance(image_input, torch.Tensor):
             return image_input
         if isinstance(image_input, np.ndarray):
+            if self.device_preprocess and image_input.dtype == np.uint8 and image_input.ndim in (2, 3):
+                from .pipeline import DevicePreprocessor
+                hw = tuple(image_input.shape[:2])
+                pre = self._pre.get(hw)
+                if pre is None:
+                    pre = self._pre[hw] = DevicePreprocessor(hw, train=False, device=self.device)
+                frame = torch.from_numpy(np.ascontiguousarray(image_input))[None].to(self.device, non_blocking=True)
+                return pre(frame)[0]
             if image_input.ndim == 2:
                 image_input = np.stack([image_input] * 3, axis=-1)
             from PIL import Image
