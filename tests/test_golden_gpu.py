@@ -76,3 +76,17 @@ def test_real_images_to_labels(dev, tmp_path):
     assert sorted(folder) == sorted(c + ".png" for c in CLASSES)
     for c, r in zip(CLASSES, res):
         assert folder[c + ".png"].prediction == r.prediction
+    # the same calls with the resize / normalise done on the GPU: the model sees the same tensor, bit for bit
+    # (the fixtures are 224x224 already; an up-sized copy exercises the resampling)
+    res_dev = predict_batch(model, imgs, classes, dev, top_k=3, device_preprocess=True)
+    for a, b in zip(res, res_dev):
+        assert np.array_equal(a.raw_logits, b.raw_logits)
+    big = [im.convert("RGB").resize((368, 201), Image.BILINEAR) for im in imgs[:4]]
+    r_host = predict_batch(model, big, classes, dev, top_k=1)
+    r_dev = predict_batch(model, big, classes, dev, top_k=1, device_preprocess=True)
+    for a, b in zip(r_host, r_dev):
+        assert np.array_equal(a.raw_logits, b.raw_logits)
+    mixed = [big[0], imgs[1]]   # different sizes: falls back to the host transform
+    assert len(predict_batch(model, mixed, classes, dev, device_preprocess=True)) == 2
+    folder_dev = predict_folder(model, os.path.join(GOLD, "images"), classes, dev, device_preprocess=True)
+    assert {k: v.prediction for k, v in folder_dev.items()} == {k: v.prediction for k, v in folder.items()}

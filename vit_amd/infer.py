@@ -114,12 +114,36 @@ def postprocess(logits: torch.Tensor, classes: Sequence[str], confidence_thresho
     return out
 
 
+_DEVICE_PRE: dict = {}
+
+
+def _device_batch(images: Sequence, device: torch.device) -> Optional[torch.Tensor]:
+    """uint8 frames of one size -> the model input, resized / normalised on the GPU (vit_amd.pipeline: the arithmetic
+    of `preprocess`, bit for bit); None when the frames differ in size or are not 8-bit."""
+    arrs = []
+    for im in images:
+        a = im if isinstance(im, np.ndarray) else np.asarray(im if im.mode in ("L", "RGB", "RGBA") else im.convert("RGB"))
+        if a.dtype != np.uint8 or a.ndim not in (2, 3) or (arrs and a.shape != arrs[0].shape):
+            return None
+        arrs.append(a)
+    from .pipeline import DevicePreprocessor
+    hw = tuple(arrs[0].shape[:2])
+    key = (hw, str(device))
+    pre = _DEVICE_PRE.get(key)
+    if pre is None:
+        pre = _DEVICE_PRE[key] = DevicePreprocessor(hw, train=False, device=device)
+    return pre(torch.from_numpy(np.stack(arrs)).to(device, non_blocking=True))
+
+
 def predict_batch(model: CNNViTHybrid, images: Sequence, classes: Sequence[str], device: torch.device,
-                  confidence_threshold: float = 0.5, top_k: int = 3) -> List[PredictionResult]:
-    """One batched forward over PIL images / luma arrays."""
+                  confidence_threshold: float = 0.5, top_k: int = 3, device_preprocess: bool = False) -> List[PredictionResult]:
+    """One batched forward over PIL images / luma arrays.  device_preprocess: resize / normalise same-sized 8-bit
+    frames on the GPU instead of with Pillow on the host (same tensor)."""
     if len(images) == 0:
         return []
-    x = torch.stack([preprocess(im) for im in images]).to(device)
+    x = _device_batch(images, device) if device_preprocess else None
+    if x is None:
+        x = torch.stack([preprocess(im) for im in images]).to(device)
     with torch.no_grad():
         logits = model(x)
     return postprocess(logits, classes, confidence_threshold, top_k)
@@ -141,7 +165,8 @@ def predict_single(model: CNNViTHybrid, image_path: str, classes: list, device: 
 
 
 def predict_folder(model: CNNViTHybrid, folder_path: str, classes: list, device: torch.device,
-                   confidence_threshold: float = 0.5, batch_size: int = 64) -> Dict[str, PredictionResult]:
+                   confidence_threshold: float = 0.5, batch_size: int = 64,
+                   device_preprocess: bool = False) -> Dict[str, PredictionResult]:
     from PIL import Image
     paths = [p for p in sorted(Path(folder_path).iterdir()) if p.suffix.lower() in IMAGE_EXTENSIONS
              and validate_input(str(p))[0]]
@@ -149,7 +174,8 @@ def predict_folder(model: CNNViTHybrid, folder_path: str, classes: list, device:
     for i in range(0, len(paths), batch_size):
         chunk = paths[i:i + batch_size]
         imgs = [Image.open(p).convert("RGB") for p in chunk]
-        for p, r in zip(chunk, predict_batch(model, imgs, classes, device, confidence_threshold, top_k=1)):
+        for p, r in zip(chunk, predict_batch(model, imgs, classes, device, confidence_threshold, top_k=1,
+                                             device_preprocess=device_preprocess)):
             results[p.name] = r
     return results
 
