@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 7
+#define RVIT_ABI_VERSION 8
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -145,6 +145,13 @@ int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, i
 int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extra, const void* X, int64_t ldx,
                     int x_row_group, int x_row_extra, float* dW, int64_t ldw, int64_t M, int N, int N_store, int K,
                     int splits, void* stream);
+
+/* Weight AND bias gradient of a Linear in one launch: dW[N_store,K] += dY^T . X as rvit_wgrad_bf16 (no row remaps) and
+ * dbias[N_store] += column sums of dY (autograd of the encoder's nn.Linear layers, train_vit.py:141-171, run by
+ * train_vit.py:939).  For N > 64 the sums ride the matrix pipe of the workgroups that own the first K tile (one extra
+ * MFMA per four); for N <= 64 (the classifier head) it is the weight-gradient kernel followed by rvit_colsum_bf16. */
+int rvit_linear_wgrad_bias_bf16(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw,
+                                float* dbias, int64_t M, int N, int N_store, int K, int splits, void* stream);
 
 /* Weight gradient of the NHWC convolution: dW[Cout, KH*KW*seg_len] += dy^T . gather(x), same
  * geometry arguments and weight layout as rvit_conv2d_fwd_bf16. */

@@ -40,6 +40,52 @@ def test_wgrad_plain(dev, M, N, K, splits):
     _close(dw, ref, 1e-3, 1e-3 * math.sqrt(M), "wgrad")
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(1000, 256, 256, 0), (777, 768, 264, 3), (300, 136, 72, 2), (64, 16, 128, 1),
+                                          (37, 128, 256, 0),
+                                          # eight-wave variant; ragged M, partial N / K tiles
+                                          (4100, 256, 384, 1), (5000, 1024, 256, 2), (3000, 136, 200, 1)])
+def test_linear_wgrad_bias(dev, M, N, K, splits):
+    """Weight and bias gradient in one launch == wgrad + colsum (train_vit.py:141-171 Linears)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    dy = _bf(torch.randn(M, N, generator=g))
+    x = _bf(torch.randn(M, K, generator=g))
+    init, binit = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    dw, db = init.clone().to(dev), binit.clone().to(dev)
+    ops.linear_wgrad_bias(dy.to(dev), x.to(dev), dw, db, splits=splits)
+    _close(dw, init + dy.float().T @ x.float(), 1e-3, 1e-3 * math.sqrt(M), "wgrad")
+    _close(db, binit + dy.float().sum(0), 1e-3, 1e-3 * math.sqrt(M), "bias grad")
+    # same weight gradient as the plain entry (atomics order aside), same sums as colsum
+    dw2, db2 = init.clone().to(dev), binit.clone().to(dev)
+    ops.wgrad(dy.to(dev), x.to(dev), dw2, splits=splits)
+    ops.colsum(dy.to(dev), db2)
+    _close(dw, dw2.cpu(), 1e-5, 1e-4 * math.sqrt(M), "wgrad vs plain entry")
+    _close(db, db2.cpu(), 1e-5, 1e-4 * math.sqrt(M), "bias grad vs colsum")
+
+
+def test_linear_wgrad_bias_exact_and_padded(dev):
+    """Small integers (exact sums) and the padded-logit head (N = 16, 11 stored rows)."""
+    from vit_amd import ops
+    M, N, K = 4096 + 40, 256, 128
+    dy = _bf((torch.arange(M * N).reshape(M, N) % 7 - 3).float())
+    x = _bf((torch.arange(M * K).reshape(M, K) % 5 - 2).float())
+    for splits in (1, 4):
+        dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+        ops.linear_wgrad_bias(dy.to(dev), x.to(dev), dw, db, splits=splits)
+        assert torch.equal(dw.cpu(), dy.float().T @ x.float())
+        assert torch.equal(db.cpu(), dy.float().sum(0))
+    g = torch.Generator().manual_seed(5)
+    B, C = 37, 11
+    dl = torch.zeros(B, 16)
+    dl[:, :C] = torch.randn(B, C, generator=g)
+    dl = _bf(dl)
+    h = _bf(torch.randn(B, K, generator=g))
+    dw, db = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev)
+    ops.linear_wgrad_bias(dl.to(dev), h.to(dev), dw, db, n_store=C)
+    _close(dw, dl[:, :C].float().T @ h.float(), 1e-3, 1e-3, "head wgrad")
+    _close(db, dl[:, :C].float().sum(0), 1e-3, 1e-3, "head bias grad")
+
+
 def test_wgrad_exact_asymmetric(dev):
     """Small integers: every product and sum is exact, so any layout/permutation error shows."""
     from vit_amd import ops
@@ -277,9 +323,13 @@ def test_batchnorm_train_fwd_bwd(dev, M, C, relu, with_res):
     zr = (yr - mean) / torch.sqrt(var + 1e-5) * gr + br
     if with_res:
         zr = zr + res.float()
+    pre = zr.detach()
     if relu:
         zr = torch.relu(zr)
     zr.backward(dz.float())
+    # elements whose pre-activation is within rounding of 0 may take either ReLU branch (the batch statistics are float
+    # atomics, so their last bits move from run to run): their dy is not compared, the channel sums hardly notice them
+    sure = pre.abs() > 1e-3 if relu else torch.ones_like(pre, dtype=torch.bool)
     # device
     yd, dzd = y.to(dev).view(1, 1, M, C), dz.to(dev).view(1, 1, M, C)
     fs = torch.zeros(2 * C, device=dev)
@@ -308,7 +358,8 @@ def test_batchnorm_train_fwd_bwd(dev, M, C, relu, with_res):
 
     dy, dg, db, dzm = backward(z=z)
     scale = max(1.0, yr.grad.abs().max().item())
-    assert (dy.view(M, C).float().cpu() - yr.grad).abs().max().item() <= 0.02 * scale
+    assert ((dy.view(M, C).float().cpu() - yr.grad).abs() * sure).max().item() <= 0.02 * scale
+    assert (~sure).sum().item() <= 2e-3 * sure.numel()
     assert torch.allclose(dg.cpu(), gr.grad, rtol=2e-2, atol=0.05 * max(1.0, gr.grad.abs().max().item()) * 0.1 + 0.5)
     assert torch.allclose(db.cpu(), br.grad, rtol=2e-2, atol=0.5)
     if relu:

@@ -212,6 +212,23 @@ int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extr
   return rvit_wgrad_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_linear_wgrad_bias_bf16(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw,
+                                float* dbias, int64_t M, int N, int N_store, int K, int splits, void* stream) {
+  RVIT_CHECK_ARG(dbias, "linear_wgrad_bias: null dbias");
+  WgradArgs a{};
+  a.dY = (const bf16*)dY; a.ldy = ldy;
+  a.X = (const bf16*)X; a.ldx = ldx;
+  a.dW = dW; a.ldw = ldw; a.M = M; a.N = N; a.N_store = N_store; a.K = K; a.mode = 0; a.splits = splits;
+  if (N > 64) {
+    a.dbias = dbias;
+    return rvit_wgrad_dispatch(a, (hipStream_t)stream);
+  }
+  // narrow outputs (the classifier head): the four-wave narrow kernel has no spare wave for the sums
+  const int rc = rvit_wgrad_dispatch(a, (hipStream_t)stream);
+  if (rc != RVIT_OK) return rc;
+  return rvit_colsum_impl(dY, ldy, dbias, M, N_store, 0, 0, (hipStream_t)stream);
+}
+
 int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, int splits,
                            void* stream) {

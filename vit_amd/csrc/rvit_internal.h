@@ -108,6 +108,7 @@ struct WgradArgs {
   int N, N_store, K;
   int mode;        // 0 plain, 1 gather
   int H, W, Cpix, Ho, Wo, KW, stride, pad, seg_len;
+  float* dbias;    // optional [N_store] fp32: += column sums of dY (plain mode, N > 64; the dispatcher checks)
   int splits;      // 0 = auto; > 0 M splits of the implicit-GEMM kernel; -1 force that kernel; -2 force the direct 3x3 kernel
 };
 

@@ -19,6 +19,7 @@ namespace {
 
 __device__ uint4 g_zero_page_w[4];
 
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
@@ -146,6 +147,12 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Bias gradient (column sums of dY) on the matrix pipe: the waves that own the first K tile's left half also
+  // multiply each dY fragment i with a B operand that is 1 in column i and 0 elsewhere, all into ONE accumulator:
+  // bsum[row 4g+r][col i] = sum_m dY[m][16i + 4g + r].  Four MFMAs per 16, in a loop bound by the L2->LDS fill.
+  f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool with_bias = false;
+  if constexpr (!GATHER && !NARROW) with_bias = p.dbias != nullptr && tile_k == 0 && wk == 0;
 
   // transposing-read geometry of this lane
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
@@ -186,6 +193,18 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+      if constexpr (!GATHER && !NARROW) {
+        if (with_bias) {
+          int col = lane & 15;
+          asm volatile("" : "+v"(col));  // rebuilt per step: four hoisted selector tuples would not fit 128 VGPRs
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const short one = col == i ? (short)0x3f80 : (short)0;  // bf16 1.0
+            const s16x8 sel = s16x8{one, one, one, one, one, one, one, one};
+            bsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], __builtin_bit_cast(bf16x8, sel), bsum, 0, 0, 0);
+          }
+        }
+      }
     }
     stage ^= 1;
   }
@@ -195,6 +214,15 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
 
   // ---- restage through LDS and add whole 256-byte rows atomically ---------------------------------
   // lane holds D[row n = 16i + 4g + r][col k = 16j + (lane&15)]
+  if constexpr (!GATHER && !NARROW) {
+    if (with_bias && (lane & 15) < 4) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + 16 * (lane & 15) + 4 * g + r;
+        if (n < p.N_store) atomicAdd(p.dbias + n, bsum[r]);
+      }
+    }
+  }
   constexpr int EP = 64 * 4 + 16;  // fp32 row pitch of the wave-private staging area (32 rows)
   char* ep = smem + wave * (32 * EP);
   const int fr = lane & 15;
@@ -236,6 +264,7 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
                    "wgrad: bad gather geometry");
     RVIT_CHECK_ARG(a.M < 0x7fffffffL && a.Ho * a.Wo < 32768 * 4 && a.Wo < 32768, "wgrad: gather index range");
   }
+  RVIT_CHECK_ARG(!a.dbias || (a.mode == 0 && a.N > 64), "wgrad: the fused bias gradient needs a plain Linear with N > 64");
   if (a.M == 0) return RVIT_OK;
   // 3x3 / stride 1 convs: LDS-resident patch kernel (wgrad3x3.hip).  splits: 0 = automatic choice, -2 forces it,
   // -1 or an explicit split count keep the implicit-GEMM kernel below (tests compare the two)

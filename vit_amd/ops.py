@@ -458,6 +458,25 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, rows: Optional
     return dw
 
 
+def linear_wgrad_bias(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dbias: torch.Tensor, *,
+                      rows: Optional[int] = None, n_store: Optional[int] = None, splits: int = 0) -> torch.Tensor:
+    """dw[N_store,K] += dy[M,N].T @ x[M,K] and dbias[N_store] += dy.sum(0), one launch (two when N <= 64)."""
+    _need_cuda(dy, x, dw, dbias)
+    My, N, ldy = _rows2d(dy, "linear_wgrad_bias dy")
+    Mx, K, ldx = _rows2d(x, "linear_wgrad_bias x")
+    M = rows if rows is not None else min(My, Mx)
+    ns, Kw, ldw = _rows2d(dw, "linear_wgrad_bias dw")
+    n_store = ns if n_store is None else n_store
+    if dy.dtype != BF16 or x.dtype != BF16 or dw.dtype != torch.float32 or Kw != K or n_store > N or n_store > ns:
+        raise ValueError(f"linear_wgrad_bias: bad operands dy{tuple(dy.shape)} x{tuple(x.shape)} dw{tuple(dw.shape)}")
+    _vec_f32(dbias, n_store, "linear_wgrad_bias: dbias")
+    with _Span("wgrad_bf16", 2 * M * N * K, (M * N + M * K) * 2 + n_store * K * 4):
+        check(_lib.load().rvit_linear_wgrad_bias_bf16(dy.data_ptr(), ldy, x.data_ptr(), ldx, dw.data_ptr(), ldw,
+                                                      dbias.data_ptr(), M, N, n_store, K, splits, _stream()),
+              "rvit_linear_wgrad_bias_bf16")
+    return dw
+
+
 def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
                  seg_len: Optional[int] = None, splits: int = 0) -> torch.Tensor:
     """dw[Cout, kh*kw*seg] += dy^T gather(x); dy bf16 [B,Ho,Wo,Cout], x bf16 [B,H,W,Cpix], dw fp32."""

@@ -587,8 +587,7 @@ class TrainEngine:
             g("head.3.bias").copy_(b["tmp16"][:C])
             ops.gemm(dl16, P["h3_wt"], b["d_h0"], gate=b["u0"], gate_mode="gelu_grad",
                      drop=("post_act", dp, sd(SITE_HEAD)))
-            ops.wgrad(b["d_h0"], b["cls_ln"], g2("head.0.weight", E // 2))
-            ops.colsum(b["d_h0"], g("head.0.bias"))
+            ops.linear_wgrad_bias(b["d_h0"], b["cls_ln"], g2("head.0.weight", E // 2), g("head.0.bias"))
             dcls = ops.gemm(b["d_h0"], P["h0_wt"], b["d_cls"])
         ops.layernorm_bwd(dcls, cls_rows, cs[0], cs[1], m.norm.weight.detach(), dx_cls, g("norm.weight"),
                           g("norm.bias"), accumulate=False, dx_bf16=dxb_cls)
@@ -603,12 +602,10 @@ class TrainEngine:
             dy = dxs_bf  # gradient of the block output; dropout2 masks what reaches linear2
             if dp > 0.0:
                 dy = ops.dropout_apply(dxs_bf, b["d_e"], dp, sd(_layer_site(i, SITE_FC2)))
-            ops.wgrad(dy, b["h"][i], g2(p + "linear2.weight", E))
-            ops.colsum(dy, g(p + "linear2.bias"))
+            ops.linear_wgrad_bias(dy, b["h"][i], g2(p + "linear2.weight", E), g(p + "linear2.bias"))
             ops.gemm(dy, W["fc2_wt"], b["d_4e"], gate=b["u"][i], gate_mode="gelu_grad",
                      drop=("post_act", dp, sd(_layer_site(i, SITE_FFN))))
-            ops.wgrad(b["d_4e"], b["ln2"][i], g2(p + "linear1.weight", 4 * E))
-            ops.colsum(b["d_4e"], g(p + "linear1.bias"))
+            ops.linear_wgrad_bias(b["d_4e"], b["ln2"][i], g2(p + "linear1.weight", 4 * E), g(p + "linear1.bias"))
             ops.gemm(b["d_4e"], W["fc1_wt"], b["d_e"])
             ops.layernorm_bwd(b["d_e"], xm, st[2], st[3], Lm.norm2.weight.detach(), dx2, g(p + "norm2.weight"),
                               g(p + "norm2.bias"), accumulate=True, dx_bf16=dxs_bf)
@@ -616,13 +613,11 @@ class TrainEngine:
             dy = dxs_bf
             if dp > 0.0:
                 dy = ops.dropout_apply(dxs_bf, b["d_e2"], dp, sd(_layer_site(i, SITE_PROJ)))
-            ops.wgrad(dy, b["att"][i], g2(p + "self_attn.out_proj.weight", E))
-            ops.colsum(dy, g(p + "self_attn.out_proj.bias"))
+            ops.linear_wgrad_bias(dy, b["att"][i], g2(p + "self_attn.out_proj.weight", E), g(p + "self_attn.out_proj.bias"))
             ops.gemm(dy, W["out_wt"], b["d_e"])
             ops.attention_bwd(b["qkv"][i], b["att"][i], b["d_e"], b["lse"][i], b["d_3e"], B, S, H, drop_p=dp,
                               drop_seed=sd(_layer_site(i, SITE_ATTN)))
-            ops.wgrad(b["d_3e"], b["ln1"][i], g2(p + "self_attn.in_proj_weight", 3 * E))
-            ops.colsum(b["d_3e"], g(p + "self_attn.in_proj_bias"))
+            ops.linear_wgrad_bias(b["d_3e"], b["ln1"][i], g2(p + "self_attn.in_proj_weight", 3 * E), g(p + "self_attn.in_proj_bias"))
             ops.gemm(b["d_3e"], W["qkv_wt"], b["d_e"])
             ops.layernorm_bwd(b["d_e"], xi, st[0], st[1], Lm.norm1.weight.detach(), dx2, g(p + "norm1.weight"),
                               g(p + "norm1.bias"), accumulate=True, dx_bf16=dxs_bf)
