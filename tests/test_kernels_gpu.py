@@ -23,7 +23,7 @@ def _close(got, ref, rtol, atol, what=""):
     assert bad == 0, f"{what}: {bad}/{err.numel()} out of tolerance, max err {err.max().item():.4g}"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 256), (128, 128, 64), (1000, 768, 200), (77, 11, 128), (64, 1024, 264)])
 def test_gemm_plain(dev, M, N, K, tile):
     from vit_amd import ops
@@ -37,6 +37,32 @@ def test_gemm_plain(dev, M, N, K, tile):
     outb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     ops.gemm(a.to(dev), w.to(dev), outb, tile=tile)
     _close(outb, ref, 1.0 / 128, 1e-3, "gemm bf16 out")
+
+
+@pytest.mark.parametrize("M,N,K,auto", [(700, 520, 328, False), (256, 256, 64, False), (1000, 72, 1024, False),
+                                        (8192 + 40, 8192, 512, True), (50432, 768, 2048, True)])
+def test_gemm_256x256_tile_bit_identical(dev, M, N, K, auto):
+    """The 256x256 tile (tile 4; what large encoder Linears run) contracts K in the same order as the 256x64 tile:
+    identical bits through every epilogue form, ragged M / N / K tiles included; `auto` shapes are ones the
+    dispatcher sends to it by itself."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias, scale = torch.randn(N, generator=g).to(dev), (torch.rand(N, generator=g) + 0.5).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    outs = []
+    for tile in (1, 0 if auto else 4):
+        o1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(a, w, o1, bias=bias, scale=scale, residual=res, act="gelu", preact=pre, tile=tile)
+        o2 = torch.empty(M, N, dtype=torch.float32, device=dev)
+        ops.gemm(a, w, o2, tile=tile)
+        outs.append((o1, pre, o2))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    if M <= 1024:
+        _close(outs[1][2], a.float().cpu() @ w.float().cpu().T, 1e-4, 1e-4, "256x256 f32 out")
 
 
 def test_gemm_identity_asymmetric(dev):

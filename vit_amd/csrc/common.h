@@ -45,15 +45,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact-erf GELU (torch nn.GELU(approximate='none'), activation='gelu')
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+// erf-form GELU (torch nn.GELU(approximate='none'), activation='gelu').  The library erff costs ~45 vector-ALU
+// instructions per element (two branches, both taken by a wave): in the fc1 epilogue that was 60-110 us of a 300 us
+// GEMM.  Here Phi(x) = 0.5 (1 + erf(x / sqrt 2)) comes from the rational approximation 7.1.26 of Abramowitz & Stegun,
+// |error in erf| <= 1.5e-7 (the size of an fp32 rounding; outputs and saved activations are bf16, 2^-9 relative),
+// branch-free: one v_rcp_f32, one v_exp_f32, six fused multiply-adds.  tail = 1 - Phi(|x|).
+__device__ __forceinline__ float gelu_tail(float ax, float e) {  // e = exp(-x^2 / 2)
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  float q = fmaf(t, 1.061405429f, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  return 0.5f * q * t * e;
 }
-// d/dx gelu_erf
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x);
+  const float tail = gelu_tail(ax, __expf(-0.5f * x * x));
+  return x >= 0.f ? fmaf(-x, tail, x) : x * tail;  // x Phi(x); Phi(-a) = tail(a)
+}
+// d/dx gelu_erf = Phi(x) + x phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const float e = __expf(-0.5f * x * x);
+  const float tail = gelu_tail(fabsf(x), e);
+  const float cdf = x >= 0.f ? 1.0f - tail : tail;
+  return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
 // Counter-based dropout (nn.Dropout of train_vit.py:100,107,125 and the attention-probability

@@ -11,7 +11,8 @@
 //     NHWC activation: the A operand row for output pixel m and k-chunk (kh,kw,c0..) is a
 //     contiguous channel run of the input pixel, gathered with a bounds predicate (zero pad).
 //
-// Structure (gfx950): 2/4/8 waves, each owning a 32x64 slice of a {64,128,256}x64 output tile, BK=64.  Operand tiles go
+// Structure (gfx950): 2/4/8 waves, each owning a 32x64 slice of a {64,128,256}x64 output tile (large products: sixteen
+// waves of 64x64 on a 256x256 tile), BK=64.  Operand tiles go
 // global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into a 3-deep ring: tile
 // kt+2 is issued while tile kt is consumed, the wave waits with a COUNTED vmcnt so that one tile
 // stays in flight across the single raw s_barrier per K tile.  LDS rows are 128 B; the 16-byte
@@ -238,29 +239,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
   // 8 lanes instead of 8-byte pieces strided over 16 rows.
   __builtin_amdgcn_s_barrier();  // every wave is done reading the operand ring
   constexpr int EP_PITCH = WN * 4 + 16;
-  static_assert(WAVES_N == 1 && WN == 64, "epilogue assumes one wave spans the 64-column tile");
-  static_assert(WAVES_M * WM * EP_PITCH <= STAGES * TILE_BYTES, "epilogue staging exceeds the ring");
-  char* ep = smem + wave * (WM * EP_PITCH);
-#pragma unroll
-  for (int i = 0; i < MR; ++i)
-#pragma unroll
-    for (int j = 0; j < NR; ++j)
-      *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i][j];
-  __syncthreads();
+  static_assert(WN == 64, "epilogue assumes 64-column wave tiles");
+  // rows staged per pass: the whole wave tile when that fits the ring, else 16 at a time (the 256x256 tile)
+  constexpr int EP_ROWS = (WAVES_M * WAVES_N * WM * EP_PITCH <= STAGES * TILE_BYTES) ? WM : 16;
+  static_assert(WAVES_M * WAVES_N * EP_ROWS * EP_PITCH <= STAGES * TILE_BYTES, "epilogue staging exceeds the ring");
+  char* ep = smem + wave * (EP_ROWS * EP_PITCH);
   const int er = lane >> 3, ec = (lane & 7) * 8;
-  const int n = bn0 + ec;
+  const int n = bn0 + wn * WN + ec;
 #pragma unroll
-  for (int pass = 0; pass < WM / 8; ++pass) {
-    const int row = pass * 8 + er;
-    const long m = bm0 + wm * WM + row;
-    if (m >= p.M || n >= p.N) continue;
-    float v[8];
-    {
-      const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4);
-      const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4 + 16);
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+  for (int i0 = 0; i0 < MR; i0 += EP_ROWS / 16) {
+    if (i0 > 0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EP_ROWS / 16; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i0 + i][j];
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < EP_ROWS / 8; ++pass) {
+      const int row = pass * 8 + er;
+      const long m = bm0 + wm * WM + i0 * 16 + row;
+      if (m >= p.M || n >= p.N) continue;
+      float v[8];
+      {
+        const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4);
+        const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4 + 16);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      }
+      rvit_gemm_epilogue_row8(p, v, m, n);
     }
-    rvit_gemm_epilogue_row8(p, v, m, n);
   }
 }
 
@@ -337,8 +344,16 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   // stages (80 KB -> 2 workgroups = 16 waves per CU) wins on every stem / encoder shape; smaller
   // tiles only when the problem cannot fill the chip.
   const long n64 = (a.N + 63) / 64;
+  // 256x256 tile, sixteen waves of 64x64 in ONE workgroup per CU (128 KB of LDS): 2.5x fewer L2 -> LDS bytes per MAC
+  // than 256x64 and 0.5 instead of 0.75 fragment reads per MFMA; same K order, so the results are bit-identical.
+  // 1.2 vs 0.9 PFLOP/s at 4096^3, 825 vs 583 TFLOP/s on the ViT-B qkv shape (profiles/r01_gemm_256x256.txt); it needs
+  // enough tiles for whole rounds over the 256 CUs and, with few rounds, a long K loop to pay for the un-overlapped
+  // prologue / epilogue of a workgroup that has the CU to itself.
+  const long t256 = ((a.M + 255) / 256) * (long)((a.N + 255) / 256);
+  const bool big = a.mode == 0 && a.K >= 512 && t256 >= 512 && (t256 >= 1024 || a.K >= 2048);
   int cfg;
   if (forced) cfg = forced;
+  else if (big) cfg = 4;
   else if (((a.M + 255) / 256) * n64 >= 384) cfg = 1;
   else if (((a.M + 127) / 128) * n64 >= 256) cfg = 2;
   else cfg = 3;
@@ -346,6 +361,7 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     case 1: return launch_cfg<256, 64, 8, 1, 2>(a, stream);
     case 2: return launch_cfg<128, 64, 4, 1, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 1, 2>(a, stream);
+    case 4: return launch_cfg<256, 256, 4, 4, 2>(a, stream);
     // 64x64 wave tiles (<256,64,4>, <128,64,2>, <512,64,8>: fewer LDS reads per MFMA) measured 20-35 % slower:
     // this loop is latency-bound and wants the 16 waves per CU (profiles/r01_tile_sweep_wave64.txt)
     default: rvit_set_error("gemm: unknown tile config %d", cfg); return RVIT_EINVAL;
