@@ -141,7 +141,8 @@ int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, i
 /* Weight gradient of a Linear: dW[N_store,K] += dY[M,N]^T . X[M,K] (fp32 atomics, accumulates like
  * autograd's .grad).  dY: bf16 [.,ldy], X: bf16 [.,ldx], optional row remaps; N, K, ldy, ldx
  * multiples of 8; rows n >= N_store of the product are discarded (padded logits).
- * splits: number of M partitions (0 = automatic). */
+ * splits: number of M partitions (0 = automatic; -3 / -4 force / forbid the sixteen-wave 256x256-tile variant that
+ * long plain products run, for tests). */
 int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extra, const void* X, int64_t ldx,
                     int x_row_group, int x_row_extra, float* dW, int64_t ldw, int64_t M, int N, int N_store, int K,
                     int splits, void* stream);

@@ -63,6 +63,42 @@ def test_linear_wgrad_bias(dev, M, N, K, splits):
     _close(db, db2.cpu(), 1e-5, 1e-4 * math.sqrt(M), "bias grad vs colsum")
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 264, 520), (64, 256, 256), (4100, 1024, 384), (50432, 768, 768), (1000, 72, 1032)])
+def test_wgrad_sixteen_wave_tile(dev, M, N, K):
+    """The 256x256-tile weight-gradient variant (splits=-3 forces it; what ViT-B/L Linears run) against the 128x128
+    kernel (splits=-4) and against torch: ragged M, partial N / K tiles in both sub-tiles, with and without bias sums."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + 2)
+    dy = _bf(torch.randn(M, N, generator=g)).to(dev)
+    x = _bf(torch.randn(M, K, generator=g)).to(dev)
+    init, binit = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    res = []
+    for sp in (-3, -4):
+        dw, db, dw2 = init.clone().to(dev), binit.clone().to(dev), init.clone().to(dev)
+        ops.linear_wgrad_bias(dy, x, dw, db, splits=sp)
+        ops.wgrad(dy, x, dw2, splits=sp)
+        res.append((dw, db, dw2))
+    tol = 1e-4 * math.sqrt(M)
+    _close(res[0][0], res[1][0].cpu(), 1e-5, tol, "W16 dw vs 128x128")
+    _close(res[0][1], res[1][1].cpu(), 1e-5, tol, "W16 dbias vs 128x128")
+    _close(res[0][2], res[0][0].cpu(), 1e-5, tol, "W16 dw with / without bias sums")
+    if M <= 5000:
+        _close(res[0][0], init + dy.float().cpu().T @ x.float().cpu(), 1e-3, 1e-3 * math.sqrt(M), "W16 dw vs torch")
+        _close(res[0][1], binit + dy.float().cpu().sum(0), 1e-3, 1e-3 * math.sqrt(M), "W16 dbias vs torch")
+
+
+def test_wgrad_sixteen_wave_exact(dev):
+    """Small integers: exact sums, any layout / sub-tile mix-up shows."""
+    from vit_amd import ops
+    M, N, K = 4096 + 40, 512, 384
+    dy = _bf((torch.arange(M * N).reshape(M, N) % 7 - 3).float())
+    x = _bf((torch.arange(M * K).reshape(M, K) % 5 - 2).float())
+    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    ops.linear_wgrad_bias(dy.to(dev), x.to(dev), dw, db, splits=-3)
+    assert torch.equal(dw.cpu(), dy.float().T @ x.float())
+    assert torch.equal(db.cpu(), dy.float().sum(0))
+
+
 def test_linear_wgrad_bias_exact_and_padded(dev):
     """Small integers (exact sums) and the padded-logit head (N = 16, 11 stored rows)."""
     from vit_amd import ops

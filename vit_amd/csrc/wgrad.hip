@@ -53,23 +53,31 @@ constexpr int TILE_B = TM * 256;   // bytes of one operand tile (64 rows x 128 b
 // W8 (not NARROW): eight waves; waves 0-3 contract rows 0-31 of every 64-row M tile, waves 4-7 rows 32-63, each group
 // over the full 128 x 128 output (the epilogue's atomics add the two halves).  Twice the waves per SIMD (4 with two
 // workgroups per CU), half the LDS-DMA instructions and half the MFMAs per wave between two barriers.
-template <bool GATHER, bool NARROW, bool W8>
-__global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(const WgradArgs p, int ntiles, int nsplits) {
-  static_assert(!(NARROW && W8), "the narrow variant stays on four waves");
-  constexpr int NPASS = W8 ? 2 : 4;            // DMA passes per operand tile
+// W16 (plain operands only): sixteen waves on a 256 x 256 output tile, ONE workgroup per CU.  The staged M tile is four
+// 64 x 128 sub-tiles (dY left/right, X left/right) in the layout above, one DMA pass each; every wave owns a 64 x 64
+// quadrant of one (dY sub-tile, X sub-tile) pair and contracts all 64 rows.  Half the L2 -> LDS bytes per MAC of the
+// 128 x 128 tile (the bound of this kernel on the ViT-B/L Linears).
+template <bool GATHER, bool NARROW, bool W8, bool W16 = false>
+__global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) void wgrad_bf16_kernel(const WgradArgs p, int ntiles, int nsplits) {
+  static_assert(!(NARROW && W8) && !(W16 && (NARROW || W8 || GATHER)), "variant combination");
+  constexpr int NPASS = W16 ? 1 : W8 ? 2 : 4;  // DMA passes per operand (sub-)tile
+  constexpr int TN = W16 ? 256 : 128;          // output tile edge
+  constexpr int NSUB = W16 ? 2 : 1;            // 128-column sub-tiles per operand
+  constexpr int STAGE_B = 2 * NSUB * TILE_B;   // bytes of one ring stage
   constexpr int PASS_ROWS = TM / NPASS;        // rows per pass (one 16-byte chunk slot per thread)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (dY tile + X tile)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wq = W8 ? (wave & 3) : wave;
-  const int wn = NARROW ? 0 : wq >> 1, wk = wq & 1;  // wave's 64x64 quadrant of the 128x128 output tile
+  // wave's 64x64 quadrant of the output tile: wn / wk index 64-column blocks of dY / X
+  const int wn = NARROW ? 0 : W16 ? wq >> 2 : wq >> 1, wk = W16 ? (wq & 3) : (wq & 1);
 
   // workgroup -> (output tile, M split), tiles fastest.  (Pinning a split's tiles to one XCD so its L2
   // serves their re-reads was measured and is 5-15 % SLOWER on the stem shapes: profiles/r01_wgrad_splits.txt.)
   const int tile_id = blockIdx.x % ntiles;
   const int split = blockIdx.x / ntiles;
-  const int ntk = (p.K + 127) / 128;
+  const int ntk = (p.K + TN - 1) / TN;
   const int tile_n = tile_id / ntk, tile_k = tile_id - tile_n * ntk;
-  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int n0 = tile_n * TN, k0 = tile_k * TN;
 
   // M range of this split, in 64-row tiles
   const long mtiles = (p.M + TM - 1) / TM;
@@ -104,18 +112,22 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
 
 #define ISSUE_MT(stage, mt)                                                                    \
   do {                                                                                         \
-    char* dY_dst = wave_dst + (stage) * (2 * TILE_B);                                          \
-    char* dX_dst = dY_dst + TILE_B;                                                            \
+    char* dY_dst = wave_dst + (stage) * STAGE_B;                                               \
+    char* dX_dst = dY_dst + NSUB * TILE_B;                                                     \
     _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                     \
       const long m = (mt) * TM + ps * PASS_ROWS + lrow;                                        \
       const bool m_ok = m < p.M && (mt) < mt_end;                                              \
       long yr = m;                                                                             \
-      if (p.y_row_group > 0) {                                                                 \
+      if (!W16 && p.y_row_group > 0) {                                                         \
         const long gy = m / p.y_row_group;                                                     \
         yr = gy * (p.y_row_group + p.y_row_extra) + (m - gy * p.y_row_group) + p.y_row_extra;  \
       }                                                                                        \
       const bf16* ysrc = (m_ok && n_ok) ? p.dY + yr * p.ldy + ncol : zero_src;                 \
       glds16(ysrc, dY_dst + ps * (PASS_ROWS * 256));                                           \
+      if constexpr (W16) {                                                                     \
+        const bf16* ysrc2 = (m_ok && ncol + 128 < p.N) ? p.dY + yr * p.ldy + ncol + 128 : zero_src; \
+        glds16(ysrc2, dY_dst + TILE_B);                                                        \
+      }                                                                                        \
       const bf16* xsrc = zero_src;                                                             \
       if constexpr (GATHER) {                                                                  \
         if (m_ok && k_ok) {                                                                    \
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
       } else {                                                                                 \
         if (m_ok && k_ok) {                                                                    \
           long xr = m;                                                                         \
-          if (p.x_row_group > 0) {                                                             \
+          if (!W16 && p.x_row_group > 0) {                                                     \
             const long g = m / p.x_row_group;                                                  \
             xr = g * (p.x_row_group + p.x_row_extra) + (m - g * p.x_row_group) + p.x_row_extra; \
           }                                                                                    \
@@ -139,6 +151,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
         }                                                                                      \
       }                                                                                        \
       glds16(xsrc, dX_dst + ps * (PASS_ROWS * 256));                                           \
+      if constexpr (W16) {                                                                     \
+        const bf16* xsrc2 = (xsrc != zero_src && kcol + 128 < p.K) ? xsrc + 128 : zero_src;    \
+        glds16(xsrc2, dX_dst + TILE_B);                                                        \
+      }                                                                                        \
     }                                                                                          \
   } while (0)
 
@@ -167,8 +183,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     ISSUE_MT(stage ^ 1, mt_begin + it + 1);  // past mt_end: zero pages (keeps the protocol uniform)
-    const char* sY = smem + stage * (2 * TILE_B);
-    const char* sX = sY + TILE_B;
+    const char* sY = smem + stage * STAGE_B + (W16 ? (wn >> 1) * TILE_B : 0);
+    const char* sX = smem + stage * STAGE_B + NSUB * TILE_B + (W16 ? (wk >> 1) * TILE_B : 0);
+    int fsw = f_r << 1;
+    if constexpr (W16) asm volatile("" : "+v"(fsw));  // swizzled chunk offsets rebuilt per M tile: hoisted they spill at 128 VGPRs
 #pragma unroll
     for (int ks0 = 0; ks0 < ((NARROW || W8) ? 1 : 2); ++ks0) {
       const int ks = NARROW ? (wave >> 1) : W8 ? (wave >> 2) : ks0;
@@ -176,14 +194,14 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
       const int rbase = (ks * 32 + rd_row) * 256 + rd_byte;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ch = ((wn * 8 + i * 2 + rd_chunk_lo) ^ (f_r << 1)) << 4;
+        const int ch = (((W16 ? (wn & 1) : wn) * 8 + i * 2 + rd_chunk_lo) ^ fsw) << 4;
         const bf16x4 lo = tr_read(sY + rbase + ch);
         const bf16x4 hi = tr_read(sY + rbase + 4 * 256 + ch);
         yf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ch = ((wk * 8 + j * 2 + rd_chunk_lo) ^ (f_r << 1)) << 4;
+        const int ch = (((W16 ? (wk & 1) : wk) * 8 + j * 2 + rd_chunk_lo) ^ fsw) << 4;
         const bf16x4 lo = tr_read(sX + rbase + ch);
         const bf16x4 hi = tr_read(sX + rbase + 4 * 256 + ch);
         xf[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -223,23 +241,24 @@ __global__ __launch_bounds__(W8 ? 512 : 256, W8 ? 4 : 2) void wgrad_bf16_kernel(
       }
     }
   }
-  constexpr int EP = 64 * 4 + 16;  // fp32 row pitch of the wave-private staging area (32 rows)
-  char* ep = smem + wave * (32 * EP);
+  constexpr int EP = 64 * 4 + 16;  // fp32 row pitch of the wave-private staging area
+  constexpr int EROWS = W16 ? 16 : 32;  // rows staged per pass (sixteen waves x 32 rows would not fit the ring)
+  char* ep = smem + wave * (EROWS * EP);
   const int fr = lane & 15;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int part = 0; part < 64 / EROWS; ++part) {
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+    for (int ii = 0; ii < EROWS / 16; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<float*>(ep + (ii * 16 + 4 * g + r) * EP + (j * 16 + fr) * 4) = acc[half * 2 + ii][j][r];
+          *reinterpret_cast<float*>(ep + (ii * 16 + 4 * g + r) * EP + (j * 16 + fr) * 4) = acc[part * (EROWS / 16) + ii][j][r];
     __syncthreads();
     const int k = k0 + wk * 64 + lane;
 #pragma unroll 4
-    for (int row = 0; row < 32; ++row) {
-      const int n = n0 + wn * 64 + half * 32 + row;
+    for (int row = 0; row < EROWS; ++row) {
+      const int n = n0 + wn * 64 + part * EROWS + row;
       if (n < p.N_store && k < p.K) {
         const float v = *reinterpret_cast<const float*>(ep + row * EP + lane * 4);
         atomicAdd(p.dW + (long)n * p.ldw + k, v);
@@ -273,8 +292,46 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
     d.splits = 0;
     return rvit_conv3x3_wgrad_direct(d, st);
   }
-  const long tiles = (long)((a.N + 127) / 128) * ((a.K + 127) / 128);
   const long mtiles = (a.M + TM - 1) / TM;
+  // Sixteen waves on 256 x 256 tiles, one workgroup per CU: for plain Linears with a long M range (ViT-B/L), where
+  // the 128 x 128 kernel is bound by its L2 -> LDS fill.  a.splits == -3 forces it (tests), -4 forbids it.
+  if (a.mode == 0 && a.N > 64 && a.splits != -4 && a.splits != -1 && a.splits <= 0 && a.y_row_group == 0 && a.x_row_group == 0) {
+    const long tiles16 = (long)((a.N + 255) / 256) * ((a.K + 255) / 256);
+    // one workgroup owns a CU, so whole rounds matter: as many M splits as fill ONE round of the chip (fewest atomics;
+    // measured against 2-4 rounds on the ViT-B shapes: profiles/r01_wgrad_w16.txt)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        rvit_set_error("wgrad: cannot query the device");
+        return RVIT_ELAUNCH;
+      }
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    long sp = n_cu / tiles16;
+    if (sp > (mtiles + 3) / 4) sp = (mtiles + 3) / 4;
+    if (sp < 1) sp = 1;
+    const bool pays = a.N >= 256 && a.K >= 256 && (mtiles + sp - 1) / sp >= 12;
+    if (a.splits == -3 || pays) {
+      RVIT_CHECK_ARG(tiles16 * sp < 0x7fffffffL, "wgrad: too many workgroups");
+      const size_t lds16 = 2 * 4 * TILE_B;  // 128 KB
+      static bool attr16 = false;
+      if (!attr16) {
+        if (hipFuncSetAttribute((const void*)wgrad_bf16_kernel<false, false, false, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16) != hipSuccess) {
+          rvit_set_error("wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds16);
+          return RVIT_ELAUNCH;
+        }
+        attr16 = true;
+      }
+      hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, false, true>), dim3((unsigned)(tiles16 * sp)), dim3(1024), lds16, st, a,
+                         (int)tiles16, (int)sp);
+      RVIT_CHECK_LAUNCH("wgrad_bf16");
+      return RVIT_OK;
+    }
+  }
+  const long tiles = (long)((a.N + 127) / 128) * ((a.K + 127) / 128);
   // ~1024 workgroups (two fit a CU at 64 KB LDS each; two rounds measured best on the stem shapes,
   // profiles/r01_wgrad_splits.txt).  Every split adds N*K atomics, so a split must also own a few M
   // tiles to pay for its epilogue (the encoder Linears: M = B*S is short).
