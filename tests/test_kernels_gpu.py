@@ -294,7 +294,7 @@ def test_errors_are_loud(dev):
 @pytest.mark.parametrize("cin,cout,hw,B", [(64, 64, 56, 2), (128, 128, 28, 3), (256, 256, 14, 5), (512, 512, 7, 11),
                                             (64, 128, 14, 1), (128, 64, 7, 40), (128, 256, 28, 2), (384, 128, 14, 3)])
 @pytest.mark.parametrize("plain", [False, True])
-@pytest.mark.parametrize("variant", [11, 12, 13])
+@pytest.mark.parametrize("variant", [11, 12, 13, 15])
 def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant):
     """The LDS-resident 3x3/1 kernel (tile 10, csrc/conv3x3.hip) against torch and against the gather
     kernel (tile 1): tiles that straddle image rows and image boundaries (M = B*hw*hw is not a
@@ -303,6 +303,8 @@ def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant)
     from vit_amd import ops
     if variant == 12 and (cout % 128 or cin % 128):
         pytest.skip("the 128-channel variant needs Cout (forward) and Cin (dgrad) multiples of 128")
+    if variant == 15 and (cout % 256 or cin % 256):
+        pytest.skip("the 256-channel sixteen-wave variant (layer4) needs Cout and Cin multiples of 256")
     g = torch.Generator().manual_seed(cin + cout + hw + B)
     x = _bf(torch.randn(B, hw, hw, cin, generator=g))
     w = _bf(torch.randn(cout, 3, 3, cin, generator=g) / math.sqrt(9 * cin))

@@ -56,19 +56,14 @@ constexpr int C3_PMAX = 640;  // patch pixels a workgroup can stage (DMA pass bu
 // Epilogue shared by the kernels below (same restaging as gemm.hip): accumulators go through a wave-private
 // 64-column LDS staging area so that whole 128-byte row segments reach global memory; folded-BN scale/bias,
 // residual, ReLU.  Ends the main loop with a workgroup barrier (the staging aliases patch and weight ring).
-template <int MR, int WM>
+// EP_ROWS: rows restaged per pass (the whole wave tile, or 16 at a time when sixteen waves share the LDS).
+template <int MR, int WM, int EP_ROWS = WM>
 __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4 (&acc)[MR][4], int wave, int lane, int wm,
                                             int wn, long m0, long m_last, int n0) {
   const int fr = lane & 15, fq = lane >> 4;
   __builtin_amdgcn_s_barrier();
   constexpr int EP_PITCH = 64 * 4 + 16;
-  char* ep = smem + wave * (WM * EP_PITCH);
-#pragma unroll
-  for (int i = 0; i < MR; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i][j];
-  __syncthreads();
+  char* ep = smem + wave * (EP_ROWS * EP_PITCH);
   const int er = lane >> 3, ec = (lane & 7) * 8;
   const int n = n0 + wn * 64 + ec;
   float sc[8], bi[8];
@@ -83,9 +78,18 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
     bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
   }
 #pragma unroll
-  for (int pass = 0; pass < WM / 8; ++pass) {
+  for (int i0 = 0; i0 < MR; i0 += EP_ROWS / 16) {
+  if (i0 > 0) __syncthreads();
+#pragma unroll
+  for (int i = 0; i < EP_ROWS / 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i0 + i][j];
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < EP_ROWS / 8; ++pass) {
     const int row = pass * 8 + er;
-    const long m = m0 + wm * WM + row;
+    const long m = m0 + wm * WM + i0 * 16 + row;
     if (m > m_last) continue;
     float v[8];
     {
@@ -108,6 +112,7 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
     o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>((bf16*)p.C + m * p.ldc + n) = o;
+  }
   }
 }
 
@@ -301,7 +306,7 @@ _Pragma("unroll") \
 #undef ISSUE_B
 #undef ISSUE_PATCH_PASS
 
-  c3_epilogue<MR, WM>(p, smem, acc, wave, lane, wm, wn, m0, m_last, n0);
+  c3_epilogue<MR, WM, (C3_WAVES == 16 ? 16 : WM)>(p, smem, acc, wave, lane, wm, wn, m0, m_last, n0);
 }
 
 }  // namespace
@@ -338,7 +343,7 @@ bool rvit_conv3x3_direct_ok(const GemmArgs& a) {
 template <int BN, bool DB, int C3_WAVES>
 static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream_t st) {
   int lds = (DB ? 2 : 1) * patch_bytes + 2 * BN * 128;
-  const int ep = C3_BM * (BN / 64) * (64 * 4 + 16);   // wave-private epilogue staging, all waves
+  const int ep = (C3_WAVES == 16 ? 16 * 16 : C3_BM * (BN / 64)) * (64 * 4 + 16);   // wave-private epilogue staging, all waves
   if (lds < ep) lds = ep;
   static int attr_lds = 0;
   if (lds > 65536 && lds > attr_lds) {
@@ -358,7 +363,7 @@ static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream
 }
 
 // variant: 0 = automatic, 1 = BN 64 (single patch buffer), 2 = BN 128 with two patch buffers, 3 = BN 64 with
-// 4 waves of 64 x 64, 4 = the weights-resident 64 -> 64 channel kernel (conv3x3_c64.hip; automatic where it applies:
+// 4 waves of 64 x 64, 5 = BN 256 with sixteen waves of 64 x 64, 4 = the weights-resident 64 -> 64 channel kernel (conv3x3_c64.hip; automatic where it applies:
 // a property of the layer geometry, never of the batch size)
 int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
   if (variant == 4) {
@@ -384,5 +389,12 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
     wide = true;
   }
   if (variant == 3) return c3_launch<64, false, 4>(a, patch_bytes, tile_len, st);
+  // 256 output channels per workgroup, sixteen waves of 64 x 64, one workgroup per CU: the patch is staged once per
+  // 256 instead of 64 output channels and the fragment reads per MFMA drop from 0.75 to 0.5.  Same K order (bit-identical).
+  // B=512: layer4 (512 -> 512, 7x7) 151 -> 135 us, layer3 (256 -> 256) 148 -> 144 us; automatic for >= 512 input
+  // channels (a property of the layer, never of the batch size), tile 15 forces it.
+  const bool c256_ok = (a.N & 255) == 0 && patch_bytes + 2 * 256 * 128 <= 160 * 1024;
+  if (variant == 5) RVIT_CHECK_ARG(c256_ok, "conv3x3: the 256-channel variant does not fit this geometry");
+  if (variant == 5 || (variant == 0 && c256_ok && a.Cpix >= 512)) return c3_launch<256, false, 16>(a, patch_bytes, tile_len, st);
   return wide ? c3_launch<128, true, 8>(a, patch_bytes, tile_len, st) : c3_launch<64, false, 8>(a, patch_bytes, tile_len, st);
 }

@@ -254,12 +254,15 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
     # the 3x3 / stride 1 / pad 1 convs run the LDS-resident-patch kernel (csrc/conv3x3.hip), everything else
     # the implicit-GEMM gather kernel (csrc/gemm.hip): profile them under separate names
     direct = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and seg_len is None and Cpix % 64 == 0
-              and Cout % 64 == 0 and (tile == 0 or 10 <= tile <= 14))
+              and Cout % 64 == 0 and (tile == 0 or 10 <= tile <= 15))
     # ... and among those the 64 -> 64 channel convs on 56-wide maps (layer1) the weights-resident kernel
     # (csrc/conv3x3_c64.hip; same conditions as rvit_conv3x3_c64_ok)
     c64 = (direct and tile in (0, 14) and Cpix == 64 and Cout == 64 and W == 56 and H % 4 == 0
            and not (residual is not None and act != "relu" and (scale is not None or bias is not None)))
-    with _Span("conv3x3_c64" if c64 else "conv3x3_direct" if direct else "conv2d_gather", 2 * B * Ho * Wo * Cout * true_k,
+    # ... and the 256-channel sixteen-wave variant for >= 512 input channels (layer4; csrc/conv3x3.hip, same rule as
+    # rvit_conv3x3_direct; its LDS-fit condition always holds: patches are capped at 80 KB)
+    c256 = direct and not c64 and Cout % 256 == 0 and (tile == 15 or (tile == 0 and Cpix >= 512))
+    with _Span("conv3x3_c64" if c64 else "conv3x3_c256" if c256 else "conv3x3_direct" if direct else "conv2d_gather", 2 * B * Ho * Wo * Cout * true_k,
                _nbytes(x, w, out, residual)):
         check(lib.rvit_conv2d_fwd_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cpix, seg, kh, kw, stride,
                                        pad, Ho, Wo, Cout, _ptr(scale), _ptr(bias), _ptr(residual), _ACT[act], tile,
