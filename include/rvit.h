@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 8
+#define RVIT_ABI_VERSION 9
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -326,6 +326,23 @@ int rvit_transpose_batched_bf16(const void* src, void* dst, const int64_t* table
 int rvit_preprocess_u8(const uint8_t* frames, int B, int H, int W, int C, const int32_t* hcoef, const int32_t* hbounds,
                        int hk, const int32_t* vcoef, const int32_t* vbounds, int vk, int resized, const int32_t* crop_tl,
                        int out_side, uint8_t* tmp, float noise_std, uint64_t noise_seed, float* out, void* stream);
+
+/* rvit_preprocess_u8 for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its transforms run on the host, train_vit.py:722-756).
+ * Same arguments and bit-identical output, without `tmp`: the uint8 intermediate [B][H][out_side] lives in a static
+ * device array of RVIT_PREPROCESS_STATIC_MAX_BYTES inside the library (one copy per GPU the library runs on, held
+ * until the process ends).  The call allocates and frees nothing and calls no allocating routine; the first call on
+ * a device resolves the array's address on that device (hipGetSymbolAddress) - make it outside graph capture.
+ *   - B * H * out_side > RVIT_PREPROCESS_STATIC_MAX_BYTES returns RVIT_EINVAL with a message (split the batch);
+ *   - the array of the CURRENT device is used: `stream` must belong to it (checked), as must every pointer;
+ *   - all calls on one GPU share the one array: calls that overlap on a GPU (two streams, two threads) race;
+ *     calls on one stream are ordered and safe.  Nothing needs clearing between calls (pass 1 overwrites every
+ *     byte pass 2 reads). */
+#define RVIT_PREPROCESS_STATIC_MAX_BYTES (32u << 20)
+int rvit_preprocess_u8_static(const uint8_t* frames, int B, int H, int W, int C, const int32_t* hcoef,
+                              const int32_t* hbounds, int hk, const int32_t* vcoef, const int32_t* vbounds, int vk,
+                              int resized, const int32_t* crop_tl, int out_side, float noise_std, uint64_t noise_seed,
+                              float* out, void* stream);
 
 /* One time step of nn.LSTM (batch_first, 1 or 2 directions: pass the *_r set or nulls), fp32, torch gate order
  * i,f,g,o: the temporal encoder of the sequence model (train_vit.py:188-229 TemporalEncoder, infer.py:186-227).

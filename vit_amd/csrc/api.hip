@@ -352,6 +352,14 @@ int rvit_preprocess_u8(const uint8_t* frames, int B, int H, int W, int C, const 
                               noise_std, noise_seed, out, (hipStream_t)stream);
 }
 
+int rvit_preprocess_u8_static(const uint8_t* frames, int B, int H, int W, int C, const int32_t* hcoef,
+                              const int32_t* hbounds, int hk, const int32_t* vcoef, const int32_t* vbounds, int vk,
+                              int resized, const int32_t* crop_tl, int out_side, float noise_std, uint64_t noise_seed,
+                              float* out, void* stream) {
+  return rvit_preprocess_static_impl(frames, B, H, W, C, hcoef, hbounds, hk, vcoef, vbounds, vk, resized, crop_tl,
+                                     out_side, noise_std, noise_seed, out, (hipStream_t)stream);
+}
+
 int rvit_lstm_step_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                        const float* w_ih_r, const float* w_hh_r, const float* b_ih_r, const float* b_hh_r, float* out,
                        float* c, float* gates, float* cseq, int B, int T, int In, int H, int step, void* stream) {

@@ -13,6 +13,8 @@
 //     dword loads, converted to luma in LDS, then thread x accumulates output column crop_left + x.
 //   pass 2 (preproc_v_kernel): thread (y, x) accumulates down a column of the intermediate (coalesced along x),
 //     converts to float, normalises per channel, adds counter-based Gaussian noise, writes three planes.
+#include <mutex>
+
 #include "common.h"
 #include "rvit_internal.h"
 
@@ -197,4 +199,64 @@ int rvit_preprocess_impl(const uint8_t* img, int B, int H, int W, int C, const i
                      vbounds, vk, crop, out_side, noise_std, key.k0, key.k1, out);
   RVIT_CHECK_LAUNCH("preprocess(v)");
   return RVIT_OK;
+}
+
+// ---- the entry point that allocates nothing (rvit_preprocess_u8_static, include/rvit.h) -------------------------
+// Same two kernels; the uint8 intermediate [B][H][out_side] lives in a file-scope device array instead of a
+// caller-provided buffer.  Every GPU the library runs on holds its own copy of the array (until the process ends)
+// at its own address: `scratch` below is only the host-side handle of the symbol, never a device address.  The
+// address on a device is resolved once, with that device current, and kept in pp_scratch_ptr[device]; host code
+// uses that pointer wherever the array's memory is meant.
+static __device__ __align__(256) uint8_t scratch[RVIT_PREPROCESS_STATIC_MAX_BYTES];
+
+namespace {
+constexpr int PP_MAX_DEVICES = 64;
+std::mutex pp_mu;
+uint8_t* pp_scratch_ptr[PP_MAX_DEVICES];   // guarded by pp_mu
+
+int pp_scratch_of_current_device(hipStream_t st, uint8_t** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= PP_MAX_DEVICES) {
+    rvit_set_error("preprocess(static): hipGetDevice failed or device index %d out of range: %s", dev, hipGetErrorString(e));
+    return RVIT_ELAUNCH;
+  }
+  if (st != nullptr) {   // the array of the CURRENT device is used: a stream of another device would fault
+    hipDevice_t sdev = -1;
+    e = hipStreamGetDevice(st, &sdev);
+    if (e != hipSuccess || (int)sdev != dev) {
+      rvit_set_error("preprocess(static): the stream belongs to device %d, the current device is %d", (int)sdev, dev);
+      return RVIT_EINVAL;
+    }
+  }
+  std::lock_guard<std::mutex> lk(pp_mu);
+  if (pp_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      rvit_set_error("preprocess(static): hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+      return RVIT_ELAUNCH;
+    }
+    pp_scratch_ptr[dev] = static_cast<uint8_t*>(p);
+  }
+  *out = pp_scratch_ptr[dev];
+  return RVIT_OK;
+}
+}  // namespace
+
+int rvit_preprocess_static_impl(const uint8_t* img, int B, int H, int W, int C, const int* hcoef, const int* hbounds,
+                                int hk, const int* vcoef, const int* vbounds, int vk, int resized, const int* crop,
+                                int out_side, float noise_std, uint64_t noise_seed, float* out, hipStream_t st) {
+  RVIT_CHECK_ARG(B > 0 && H > 0 && out_side > 0, "preprocess(static): bad shape B=%d H=%d out_side=%d", B, H, out_side);
+  const long need = (long)B * H * out_side;
+  RVIT_CHECK_ARG(need <= (long)RVIT_PREPROCESS_STATIC_MAX_BYTES,
+                 "preprocess(static): B*H*out_side = %ld bytes of intermediate exceed the static scratch (%ld bytes); "
+                 "split the batch or call rvit_preprocess_u8 with a caller-owned buffer",
+                 need, (long)RVIT_PREPROCESS_STATIC_MAX_BYTES);
+  uint8_t* tmp = nullptr;
+  const int rc = pp_scratch_of_current_device(st, &tmp);
+  if (rc != RVIT_OK) return rc;
+  // pass 1 writes every byte of tmp[0, B*H*out_side) that pass 2 reads: nothing has to be cleared between calls
+  return rvit_preprocess_impl(img, B, H, W, C, hcoef, hbounds, hk, vcoef, vbounds, vk, resized, crop, out_side, tmp,
+                              noise_std, noise_seed, out, st);
 }

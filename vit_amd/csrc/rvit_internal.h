@@ -77,6 +77,9 @@ int rvit_adamw_impl(float* p, const float* g, float* m, float* v, long n, float 
 int rvit_preprocess_impl(const uint8_t* img, int B, int H, int W, int C, const int* hcoef, const int* hbounds, int hk,
                          const int* vcoef, const int* vbounds, int vk, int resized, const int* crop, int out_side,
                          uint8_t* tmp, float noise_std, uint64_t noise_seed, float* out, hipStream_t st);  // preproc.hip
+int rvit_preprocess_static_impl(const uint8_t* img, int B, int H, int W, int C, const int* hcoef, const int* hbounds,
+                                int hk, const int* vcoef, const int* vbounds, int vk, int resized, const int* crop,
+                                int out_side, float noise_std, uint64_t noise_seed, float* out, hipStream_t st);
 int rvit_lstm_step_fwd_impl(const float* x, const float* const* w, float* out, float* c, float* gates, float* cseq, int B,
                             int T, int In, int H, int s, int ndir, hipStream_t st);  // lstm.hip
 int rvit_lstm_step_bwd_impl(const float* dout, const float* whh_t0, const float* whh_t1, const float* gates,

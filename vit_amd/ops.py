@@ -868,3 +868,34 @@ def preprocess_u8(frames: torch.Tensor, tables_h, tables_v, resized: int, out: t
                                              _ptr(tmp), float(noise_std), int(noise_seed) & ((1 << 64) - 1), _ptr(out),
                                              _stream()), "rvit_preprocess_u8")
     return out
+
+
+PREPROCESS_STATIC_MAX_BYTES = 32 << 20   # RVIT_PREPROCESS_STATIC_MAX_BYTES
+
+
+def preprocess_u8_static(frames: torch.Tensor, tables_h, tables_v, resized: int, out: torch.Tensor,
+                         crop_tl: Optional[torch.Tensor] = None, noise_std: float = 0.0, noise_seed: int = 0) -> torch.Tensor:
+    """preprocess_u8 through the entry point that allocates nothing (rvit_preprocess_u8_static): the intermediate
+    lives in the library's static device array; B*H*S beyond 32 MiB is refused by the library.  Calls that overlap
+    on one GPU race on that array."""
+    _need_cuda(frames, out, crop_tl, tables_h[1], tables_h[2], tables_v[1], tables_v[2])
+    if frames.dtype != torch.uint8 or not frames.is_contiguous() or frames.dim() not in (3, 4):
+        raise ValueError("preprocess_u8_static: contiguous uint8 [B,H,W,C] or [B,H,W] frames expected")
+    B, H, W = frames.shape[:3]
+    C = frames.shape[3] if frames.dim() == 4 else 1
+    S = out.shape[-1]
+    if out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != (B, 3, S, S):
+        raise ValueError("preprocess_u8_static: out must be contiguous float32 [B,3,S,S]")
+    for (ks, bounds, coef), n_in in ((tables_h, W), (tables_v, H)):
+        if bounds.dtype != torch.int32 or coef.dtype != torch.int32 or tuple(bounds.shape) != (resized, 2) \
+                or tuple(coef.shape) != (resized, ks) or not bounds.is_contiguous() or not coef.is_contiguous():
+            raise ValueError("preprocess_u8_static: malformed resampling tables")
+    if crop_tl is not None and (crop_tl.dtype != torch.int32 or tuple(crop_tl.shape) != (B, 2) or not crop_tl.is_contiguous()):
+        raise ValueError("preprocess_u8_static: crop_tl must be int32 [B,2] (top, left)")
+    with torch.cuda.device(frames.device):   # the library uses the static array of the CURRENT device
+        with _Span("preprocess_u8", 0, frames.numel() + 2 * B * H * S + out.numel() * 4):
+            check(_lib.load().rvit_preprocess_u8_static(
+                _ptr(frames), B, H, W, C, _ptr(tables_h[2]), _ptr(tables_h[1]), tables_h[0], _ptr(tables_v[2]),
+                _ptr(tables_v[1]), tables_v[0], resized, _ptr(crop_tl), S, float(noise_std),
+                int(noise_seed) & ((1 << 64) - 1), _ptr(out), _stream()), "rvit_preprocess_u8_static")
+    return out
