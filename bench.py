@@ -5,7 +5,10 @@ micro-Doppler-shaped inputs, frames/s aggregated over N GPUs (batch sharded, no 
 collective).
 
   python bench.py --gpus N --steps K --warmup W [--batch B]
-N>1 is launched by torch.distributed.run, one rank per GPU; rank 0 prints ONE JSON line.
+N>1 runs one rank per GPU over RCCL: either the caller launches the ranks (`python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`, RANK / LOCAL_RANK / WORLD_SIZE in the environment), or, when WORLD_SIZE
+is not set, this script starts that launcher itself as a CHILD process before anything touches the GPU and relays
+rank 0's JSON line and the child's exit status.  Rank 0 prints ONE JSON line.
 
 A "step" is one forward pass of the hot path (image pack -> stem -> patch embed -> encoder ->
 head) over one batch already resident in HBM.  `roofline` is measured live with HIP events around
@@ -95,6 +98,17 @@ def cpu_train_baseline(sd, cfg, steps=4, batch=32, seconds=25.0):
             "sample": f"{n} optimiser steps of batch {batch} (fp32, torch {torch.__version__}), same model / loss / optimiser"}
 
 
+def max_over_ranks(dist, dt: float, dev) -> float:
+    """MAX of the timed interval over all ranks (RCCL: a device tensor; the gloo rehearsal: a host tensor, because
+    gloo's device staging must not be used on this platform, vit_amd/dp.py)."""
+    if dist is None:
+        return dt
+    on_dev = "nccl" in str(dist.get_backend()).lower()
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def _say(rank, msg):
     if os.environ.get("RVIT_BENCH_VERBOSE"):
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
@@ -156,10 +170,7 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
     sync()
     _say(rank, "train: timed steps done")
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dist, dt, dev)
     kernels = {}
     if rank == 0 or dist is not None:  # every rank must run the same collectives
         rec = []
@@ -223,10 +234,7 @@ def vitl_infer(args, dev, dist, world, rank):
                 model(x)
             sync()
             dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = max_over_ranks(dist, dt, dev)
         res[prec] = dt
         if rank == 0 and prec == "mxfp8":
             rec = []
@@ -265,6 +273,29 @@ def vitl_infer(args, dev, dist, world, rank):
     print(json.dumps(out), flush=True)
 
 
+def spawn_ranks(n: int) -> int:
+    """`bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks of this same command line
+    as a child process (never exec: nothing here may have touched the GPU yet, and nothing has - `import torch` and
+    `device_count()` do not initialise HIP), stream its output through, return its exit status."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("RVIT_BENCH_BACKEND", "nccl") == "nccl":
+        print(f"[bench] --gpus {n} requested but {have} visible: RCCL needs one GPU per rank", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:          # rank 0's JSON line (and anything else the ranks print) passes through
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +316,12 @@ def main():
                          "vitb-train = BASELINE configs[3], ViT-B/16-scale training samples/s; "
                          "vitl-infer-fp8 = BASELINE configs[4], ViT-L/16-scale MX-fp8 inference frames/s")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's world size is used",
+              file=sys.stderr, flush=True)
 
     if os.environ.get("RVIT_BENCH_VERBOSE"):  # where is every thread after 45 s?  (hang diagnosis)
         import faulthandler
@@ -361,10 +398,7 @@ def main():
             model(x)
         sync()
         dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dist, dt, dev)
 
     # ---- per-kernel timing with HIP events on the launch stream (same steps, instrumented) ------
     roofline = None
@@ -430,14 +464,18 @@ def main():
     if not args.no_train:
         del x
         # The headline above is already measured: a secondary leg that stalls (a wedged collective, a lost peer)
-        # must not take it down.  After --train-timeout seconds every rank gives up; rank 0 still prints the line.
+        # must not lose it.  After --train-timeout seconds every rank gives up: rank 0 still prints the line, with
+        # `train.error` set, and EVERY rank exits with status 3 - a process that touched the GPU and stalled has failed.
         import threading
 
         def give_up():
+            import faulthandler
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
             if out is not None:
-                out["train"] = {"error": f"training leg did not finish within {args.train_timeout:.0f} s; skipped"}
+                out["train"] = {"error": f"training leg did not finish within {args.train_timeout:.0f} s; abandoned, exit status 3"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            sys.stderr.flush()
+            os._exit(3)
 
         dog = threading.Timer(args.train_timeout, give_up)
         dog.daemon = True

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 9
+#define RVIT_ABI_VERSION 10
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -253,11 +253,18 @@ int rvit_batch_sum_f32(const float* x, int64_t ldb, float* out, int B, int64_t n
  * in train(), train_vit.py:87; eps inside the sqrt, biased batch variance for normalisation,
  * unbiased for running_var, momentum update like torch).  C % 8 == 0, 256 % (C/8) == 0.
  *   rvit_bn_stats:  sums[0..C) += sum_m y, sums[C..2C) += sum_m y^2   (caller zeroes sums)
+ *                   workspace == NULL: partial sums meet in float atomics (fastest; the last bits vary from run
+ *                   to run).  workspace != NULL (RVIT_BN_WORKSPACE_BYTES, 4-byte aligned, its first word zero before
+ *                   the first call; consecutive calls on one stream may share it): ORDERED reduction - partials per
+ *                   workgroup, added in workgroup order by the workgroup that finishes last - the same bits on every
+ *                   run, what `torch.backends.cudnn.deterministic = True` asks of the reference (train_vit.py:50).
+ *                   rvit_bn_bwd_reduce takes the same argument.
  *   rvit_bn_apply:  z = relu?( gamma*(y-mean)*rstd + beta + residual ); updates running stats
  *                   when running_mean/var are given.  relu_mask (optional, relu only): uint8 [M, C/8],
  *                   bit k of byte (m, c/8) = z[m, 8*(c/8) + k] > 0; lets the backward kernels read one byte per
  *                   8 channels instead of z. */
-int rvit_bn_stats(const void* y, int64_t M, int C, float* sums, void* stream);
+#define RVIT_BN_WORKSPACE_BYTES ((64 + 262144) * 4)
+int rvit_bn_stats(const void* y, int64_t M, int C, float* sums, void* workspace, void* stream);
 int rvit_bn_apply(const void* y, const float* sums, const float* gamma, const float* beta, const void* residual,
                   void* z, int64_t M, int C, float eps, int relu, float momentum, float* running_mean,
                   float* running_var, void* relu_mask, void* stream);
@@ -277,7 +284,7 @@ int rvit_bn_apply_pool(const void* y, const float* sums, const float* gamma, con
  *   rvit_bn_bwd_apply:  dy = gamma*rstd*(dzm - mean(dzm) - xhat*mean(dzm*xhat)); dgamma += .., dbeta += ..;
  *                       dz_masked (optional) receives dzm = the gradient of the residual branch. */
 int rvit_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* fwd_sums, int64_t M, int C,
-                       float eps, int relu, float* bwd_sums, void* stream);
+                       float eps, int relu, float* bwd_sums, void* workspace, void* stream);
 int rvit_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* fwd_sums, const float* bwd_sums,
                       const float* gamma, void* dy, void* dz_masked, float* dgamma, float* dbeta, int64_t M, int C,
                       float eps, int relu, void* stream);

@@ -24,6 +24,8 @@ def bench(fn, iters=20):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     dev = torch.device("cuda:0")
+    ws = ops.bn_workspace(dev) if len(sys.argv) > 2 and sys.argv[2] == "ordered" else None
+    print("ordered reductions" if ws is not None else "float-atomic reductions")
     for name, hw, c in (("conv1", 112, 64), ("layer1", 56, 64), ("layer2", 28, 128), ("layer3", 14, 256), ("layer4", 7, 512)):
         y = torch.randn(B, hw, hw, c, device=dev).bfloat16()
         dz = torch.randn_like(y)
@@ -34,9 +36,9 @@ def main():
         dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
         mb = y.numel() * 2 / 1e6
         def once():
-            ops.bn_stats(y, fs)
+            ops.bn_stats(y, fs, ws)
             ops.bn_apply(y, fs, g, b, z, eps=1e-5, relu=True, relu_mask=mask)
-            ops.bn_bwd(dz, None, y, fs, bs, g, dy, dg, db, eps=1e-5, relu=True, relu_mask=mask)
+            ops.bn_bwd(dz, None, y, fs, bs, g, dy, dg, db, eps=1e-5, relu=True, relu_mask=mask, workspace=ws)
         for _ in range(3):
             once()
         rec = []

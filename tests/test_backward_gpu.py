@@ -412,6 +412,48 @@ def test_batchnorm_train_fwd_bwd(dev, M, C, relu, with_res):
                        relu_mask=mask[:-1])
 
 
+@pytest.mark.parametrize("M,C", [(1000, 64), (40 * 28 * 28, 128), (333, 512), (64 * 49, 512), (8 * 112 * 112, 64),
+                                 (5000, 1024), (9 * 196, 256)])
+def test_batchnorm_ordered_reductions_are_bit_reproducible(dev, M, C):
+    """bn_stats / bn_bwd with a workspace run the ORDERED reductions (no float atomics): ten runs give the same bits,
+    the totals agree with a float64 sum, and the workspace can be shared by consecutive calls of different shapes."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M * 3 + C)
+    y = (torch.randn(M, C, generator=g) * 1.5 + 0.3).bfloat16().to(dev).view(1, 1, M, C)
+    dz = torch.randn(M, C, generator=g).bfloat16().to(dev).view(1, 1, M, C)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    ws = ops.bn_workspace(dev)
+    other = torch.randn(1, 1, 777, 128, device=dev).bfloat16()     # a different shape through the same workspace
+
+    def run():
+        fs = torch.zeros(2 * C, device=dev)
+        ops.bn_stats(y, fs, ws)
+        ops.bn_stats(other, torch.zeros(256, device=dev), ws)
+        z = torch.empty_like(y)
+        mask = torch.zeros(M * (C // 8), dtype=torch.uint8, device=dev)
+        ops.bn_apply(y, fs, gamma, torch.zeros(C, device=dev), z, eps=1e-5, relu=True, relu_mask=mask)
+        bs = torch.zeros(2 * C, device=dev)
+        dy = torch.empty_like(y)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        ops.bn_bwd(dz, None, y, fs, bs, gamma, dy, dg, db, eps=1e-5, relu=True, relu_mask=mask, workspace=ws)
+        return fs, bs, dy, dg, db, z
+
+    first = run()
+    for _ in range(9):
+        again = run()
+        for a, b in zip(first, again):
+            assert torch.equal(a, b)
+    fs = first[0].double().cpu()
+    yf = y.view(M, C).double().cpu()
+    assert torch.allclose(fs[:C], yf.sum(0), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(fs[C:], (yf * yf).sum(0), rtol=1e-5, atol=1e-2)
+    assert int(ws[:1].view(torch.int32).item()) == 0            # the ticket counter is re-armed
+    # same results (to float round-off) as the atomic form
+    fs2 = torch.zeros(2 * C, device=dev)
+    ops.bn_stats(y, fs2)
+    assert torch.allclose(first[0], fs2, rtol=1e-5, atol=1e-2)
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 112, 112, 64), (3, 10, 14, 64), (1, 7, 9, 128)])
 def test_bn_apply_pool_fused(dev, B, H, W, C):
     """BatchNorm + ReLU + MaxPool2d(3,2,1) in one pass (the training stem entry) against the two-kernel path

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -69,10 +69,10 @@ SIGNATURES = {
     "rvit_preprocess_u8": ([P, I, I, I, I, P, P, I, P, P, I, I, P, I, P, F, U64, P, P], c_int),
     "rvit_preprocess_u8_static": ([P, I, I, I, I, P, P, I, P, P, I, I, P, I, F, U64, P, P], c_int),
     "rvit_transpose_batched_bf16": ([P, P, P, I, L, P], c_int),
-    "rvit_bn_stats": ([P, L, I, P, P], c_int),
+    "rvit_bn_stats": ([P, L, I, P, P, P], c_int),
     "rvit_bn_apply": ([P, P, P, P, P, P, L, I, F, I, F, P, P, P, P], c_int),
     "rvit_bn_apply_pool": ([P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P], c_int),
-    "rvit_bn_bwd_reduce": ([P, P, P, P, L, I, F, I, P, P], c_int),
+    "rvit_bn_bwd_reduce": ([P, P, P, P, L, I, F, I, P, P, P], c_int),
     "rvit_bn_bwd_apply": ([P, P, P, P, P, P, P, P, P, P, L, I, F, I, P], c_int),
     "rvit_maxpool3x3s2_bwd_nhwc": ([P, P, P, I, I, I, I, P], c_int),
 }

@@ -5,8 +5,8 @@
 
 extern "C" {
 
-int rvit_bn_stats(const void* y, int64_t M, int C, float* sums, void* stream) {
-  return rvit_bn_stats_impl(y, M, C, sums, (hipStream_t)stream);
+int rvit_bn_stats(const void* y, int64_t M, int C, float* sums, void* workspace, void* stream) {
+  return rvit_bn_stats_impl(y, M, C, sums, (float*)workspace, (hipStream_t)stream);
 }
 
 int rvit_bn_apply(const void* y, const float* sums, const float* gamma, const float* beta, const void* residual,
@@ -24,8 +24,8 @@ int rvit_bn_apply_pool(const void* y, const float* sums, const float* gamma, con
 }
 
 int rvit_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* fwd_sums, int64_t M, int C,
-                       float eps, int relu, float* bwd_sums, void* stream) {
-  return rvit_bn_bwd_reduce_impl(dz, z, y, fwd_sums, M, C, eps, relu, bwd_sums, (hipStream_t)stream);
+                       float eps, int relu, float* bwd_sums, void* workspace, void* stream) {
+  return rvit_bn_bwd_reduce_impl(dz, z, y, fwd_sums, M, C, eps, relu, bwd_sums, (float*)workspace, (hipStream_t)stream);
 }
 
 int rvit_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* fwd_sums, const float* bwd_sums,

@@ -82,11 +82,106 @@ __device__ __forceinline__ void red_commit(float* red, int C, int chunk, float (
   }
 }
 
-__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const bf16* __restrict__ y, long M, int C,
-                                                               float* __restrict__ sums) {
-  extern __shared__ float red[];  // [2*C]
-  for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) red[i] = 0.f;
+// Ordered form of the same reduction (ws != null): no floating-point atomics anywhere, so the 2*C totals are the
+// same bits on every run.  BatchNorm statistics feed every later activation: through bf16 storage and ReLU a last-bit
+// difference in one mean flips signs of near-zero pre-activations and, on a random-weight stem at batch 8, moves
+// gradients by ~20 % between two runs of the same step (tests/test_dp_gpu.py measured it).
+//   1. lanes that share a channel chunk combine by the xor butterfly (fixed order);
+//   2. every (wave | row group) stores its 2*C values to its own LDS slot, thread i adds the slots in slot order;
+//   3. the workgroup stores its 2*C partials to ws[64 + blockIdx.x * 2C ..]; the workgroup that takes the LAST ticket
+//      of the counter ws[0] adds the partials in workgroup order into `sums` and re-arms the counter.
+// ws: (64 + gridDim.x * 2 * C) floats, ws[0] zero before the first call; sequential calls on one stream may share it.
+__device__ __forceinline__ int det_slots(int C) { return (C >> 3) < 64 ? RED_THREADS / 64 : RED_THREADS / (C >> 3); }
+
+__device__ __forceinline__ void red_commit_det(float* red, int C, int chunk, float (&a)[8], float (&b)[8],
+                                               float* __restrict__ ws, float* __restrict__ sums) {
+  __shared__ unsigned ticket;
+  const int cpr = C >> 3, lane = threadIdx.x & 63;
+  for (int off = 32; off >= cpr; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a[k] += __shfl_xor(a[k], off, 64);
+      b[k] += __shfl_xor(b[k], off, 64);
+    }
+  }
+  const int slot = cpr < 64 ? (int)(threadIdx.x >> 6) : (int)(threadIdx.x / cpr);
+  if (cpr >= 64 || lane < cpr) {
+    float* r = red + (long)slot * 2 * C;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      r[chunk * 8 + k] = a[k];
+      r[C + chunk * 8 + k] = b[k];
+    }
+  }
   __syncthreads();
+  const int nslots = det_slots(C), cols = 2 * C, nblk = (int)gridDim.x;
+  float* part = ws + 64 + (long)blockIdx.x * cols;
+  for (int i = threadIdx.x; i < cols; i += RED_THREADS) {
+    float t = 0.f;
+    for (int sl = 0; sl < nslots; ++sl) t += red[(long)sl * cols + i];
+    part[i] = t;
+  }
+  __syncthreads();   // every thread's partial stores have been issued and waited for
+  if (threadIdx.x == 0) {
+    __threadfence();   // release (one L2 write-back per workgroup, not one per wave)
+    ticket = atomicAdd(reinterpret_cast<unsigned*>(ws), 1u);
+  }
+  __syncthreads();
+  if (ticket != (unsigned)nblk - 1u) return;
+  __threadfence();   // acquire: the other workgroups' partials
+  // The last workgroup adds the partials in a fixed association: G thread groups each add a contiguous run of
+  // workgroups in order (eight loads in flight: the partials come from HBM at ~1 us a round trip), then the G group
+  // totals are added in group order.
+  const float* all = ws + 64;
+  if (cols <= RED_THREADS) {
+    const int G = RED_THREADS / cols, g = (int)threadIdx.x / cols, i = (int)threadIdx.x - g * cols;
+    const int per = (nblk + G - 1) / G;
+    float t = 0.f;
+    if (g < G) {
+      int blk = g * per;
+      const int end = blk + per < nblk ? blk + per : nblk;
+      for (; blk + 8 <= end; blk += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(all + (long)(blk + j) * cols + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += v[j];
+      }
+      for (; blk < end; ++blk) t += __builtin_nontemporal_load(all + (long)blk * cols + i);
+    }
+    __syncthreads();   // the slot values in `red` are dead
+    if (g < G) red[g * cols + i] = t;
+    __syncthreads();
+    if (g == 0) {
+      float tot = 0.f;
+      for (int gg = 0; gg < G; ++gg) tot += red[gg * cols + i];
+      sums[i] += tot;
+    }
+  } else {
+    for (int i = threadIdx.x; i < cols; i += RED_THREADS) {
+      float t = 0.f;
+      int blk = 0;
+      for (; blk + 8 <= nblk; blk += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(all + (long)(blk + j) * cols + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += v[j];
+      }
+      for (; blk < nblk; ++blk) t += __builtin_nontemporal_load(all + (long)blk * cols + i);
+      sums[i] += t;
+    }
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(ws) = 0u;   // re-armed for the next call on this stream
+}
+
+__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const bf16* __restrict__ y, long M, int C,
+                                                               float* __restrict__ sums, float* __restrict__ ws) {
+  extern __shared__ float red[];  // [2*C]; ordered form: [slots][2*C]
+  if (!ws) {
+    for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) red[i] = 0.f;
+    __syncthreads();
+  }
   const RowSpan s = row_span(M, C, RED_THREADS);
   const long step = s.rows_per_pass;
   const bf16* base = y + s.chunk * 8;
@@ -111,6 +206,10 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const bf16* __res
     unpack8(*reinterpret_cast<const uint4*>(base + m * C), v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { a[k] += v[k]; q[k] += v[k] * v[k]; }
+  }
+  if (ws) {
+    red_commit_det(red, C, s.chunk, a, q, ws, sums);
+    return;
   }
   red_commit(red, C, s.chunk, a, q);
   __syncthreads();
@@ -272,10 +371,13 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
                                                                     const bf16* __restrict__ z,
                                                                     const bf16* __restrict__ y,
                                                                     const float* __restrict__ fsums, long M, int C,
-                                                                    float eps, int relu, float* __restrict__ bsums) {
-  extern __shared__ float red[];  // [2*C]
-  for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) red[i] = 0.f;
-  __syncthreads();
+                                                                    float eps, int relu, float* __restrict__ bsums,
+                                                                    float* __restrict__ ws) {
+  extern __shared__ float red[];  // [2*C]; ordered form: [slots][2*C]
+  if (!ws) {
+    for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) red[i] = 0.f;
+    __syncthreads();
+  }
   const RowSpan s = row_span(M, C, RED_THREADS);
   const long step = s.rows_per_pass;
   const int c0 = s.chunk * 8, cpr = C >> 3;
@@ -335,6 +437,10 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
   for (int k = 0; k < 8; ++k) {
     const float var = fmaxf(fsums[C + c0 + k] * inv_m - mean[k] * mean[k], 0.f);
     s2[k] *= 1.0f / sqrtf(var + eps);
+  }
+  if (ws) {
+    red_commit_det(red, C, s.chunk, s1, s2, ws, bsums);
+    return;
   }
   red_commit(red, C, s.chunk, s1, s2);
   __syncthreads();
@@ -470,19 +576,27 @@ long bn_blocks(long M, int C, int rows_per_thread) {
   return blocks > 2048 ? 2048 : blocks;
 }
 
-long red_blocks(long M, int C) {
+long red_blocks(long M, int C, bool ordered) {
   const long per = (long)(RED_THREADS / (C >> 3)) * 4;
   long blocks = (M + per - 1) / per;
-  return blocks > 256 ? 256 : blocks;
+  // ordered form: the last workgroup reads blocks * 2C partials on its own, so wide maps run fewer workgroups
+  const long cap = !ordered ? 256 : (C <= 128 ? 256 : (C <= 256 ? 128 : 64));
+  return blocks > cap ? cap : blocks;
+}
+size_t red_lds(int C, bool ordered) {
+  const int slots = (C >> 3) < 64 ? RED_THREADS / 64 : RED_THREADS / (C >> 3);
+  const size_t fl = (size_t)(ordered ? slots : 1) * 2 * C;
+  return (ordered && fl < RED_THREADS ? (size_t)RED_THREADS : fl) * sizeof(float);
 }
 
 }  // namespace
 
-int rvit_bn_stats_impl(const void* y, long M, int C, float* sums, hipStream_t st) {
+int rvit_bn_stats_impl(const void* y, long M, int C, float* sums, float* ws, hipStream_t st) {
   RVIT_CHECK_ARG(y && sums && bn_shape_ok(M, C) && rvit_aligned16(y), "bn_stats: bad arguments (M=%ld C=%d)", M, C);
-  const long blocks = red_blocks(M, C);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), 2 * C * sizeof(float), st, (const bf16*)y, M, C,
-                     sums);
+  RVIT_CHECK_ARG(!ws || (((uintptr_t)ws) & 3) == 0, "bn_stats: workspace alignment");
+  const long blocks = red_blocks(M, C, ws != nullptr);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), red_lds(C, ws != nullptr), st,
+                     (const bf16*)y, M, C, sums, ws);
   RVIT_CHECK_LAUNCH("bn_stats");
   return RVIT_OK;
 }
@@ -521,13 +635,13 @@ int rvit_bn_apply_pool_impl(const void* y, const float* sums, const float* gamma
 }
 
 int rvit_bn_bwd_reduce_impl(const void* dz, const void* z, const void* y, const float* fsums, long M, int C, float eps,
-                            int relu, float* bsums, hipStream_t st) {
+                            int relu, float* bsums, float* ws, hipStream_t st) {
   RVIT_CHECK_ARG(dz && y && fsums && bsums && (!relu || z) && bn_shape_ok(M, C), "bn_bwd_reduce: bad arguments");
   RVIT_CHECK_ARG(relu >= 0 && relu <= 2, "bn_bwd_reduce: relu is 0, 1 (z = forward output) or 2 (z = sign bits)");
   RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && (relu != 1 || rvit_aligned16(z)), "bn_bwd_reduce: alignment");
-  const long blocks = red_blocks(M, C);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), 2 * C * sizeof(float), st,
-                     (const bf16*)dz, (const bf16*)z, (const bf16*)y, fsums, M, C, eps, relu, bsums);
+  const long blocks = red_blocks(M, C, ws != nullptr);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), red_lds(C, ws != nullptr), st,
+                     (const bf16*)dz, (const bf16*)z, (const bf16*)y, fsums, M, C, eps, relu, bsums, ws);
   RVIT_CHECK_LAUNCH("bn_bwd_reduce");
   return RVIT_OK;
 }

@@ -145,7 +145,7 @@ int rvit_ce_loss_impl(const float* logits, long ldl, const long* labels, float* 
 int rvit_colsum_impl(const void* a, long lda, float* out, long M, int N, long row_group, long row_extra,
                      hipStream_t st);
 int rvit_batch_sum_impl(const float* x, long ldb, float* out, int B, long n, hipStream_t st);
-int rvit_bn_stats_impl(const void* y, long M, int C, float* sums, hipStream_t st);
+int rvit_bn_stats_impl(const void* y, long M, int C, float* sums, float* ws, hipStream_t st);
 int rvit_bn_apply_impl(const void* y, const float* sums, const float* gamma, const float* beta, const void* res,
                        void* z, long M, int C, float eps, int relu, float momentum, float* running_mean,
                        float* running_var, void* relu_mask, hipStream_t st);
@@ -153,7 +153,7 @@ int rvit_bn_apply_pool_impl(const void* y, const float* sums, const float* gamma
                             void* argmax, void* relu_mask, int B, int H, int W, int C, float eps, float momentum,
                             float* running_mean, float* running_var, hipStream_t st);
 int rvit_bn_bwd_reduce_impl(const void* dz, const void* z, const void* y, const float* fsums, long M, int C, float eps,
-                            int relu, float* bsums, hipStream_t st);
+                            int relu, float* bsums, float* ws, hipStream_t st);
 int rvit_bn_bwd_apply_impl(const void* dz, const void* z, const void* y, const float* fsums, const float* bsums,
                            const float* gamma, void* dy, void* dzm_out, float* dgamma, float* dbeta, long M, int C,
                            float eps, int relu, hipStream_t st);

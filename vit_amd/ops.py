@@ -661,13 +661,28 @@ def _map2d(t: torch.Tensor, what: str):
     return t.numel() // C, C
 
 
-def bn_stats(y: torch.Tensor, sums: torch.Tensor) -> torch.Tensor:
-    """sums[0:C] += sum y, sums[C:2C] += sum y^2 over all pixels; y bf16 [...,C]."""
-    _need_cuda(y, sums)
+BN_WORKSPACE_BYTES = (64 + 262144) * 4   # RVIT_BN_WORKSPACE_BYTES
+
+
+def bn_workspace(device) -> torch.Tensor:
+    """Zeroed workspace that switches bn_stats / bn_bwd to their ordered (run-to-run bit-identical) reductions."""
+    return torch.zeros(BN_WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+
+
+def _check_bn_ws(ws):
+    if ws is not None and (ws.dtype != torch.float32 or not ws.is_contiguous() or ws.numel() * 4 < BN_WORKSPACE_BYTES):
+        raise ValueError("bn: workspace must come from ops.bn_workspace()")
+
+
+def bn_stats(y: torch.Tensor, sums: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sums[0:C] += sum y, sums[C:2C] += sum y^2 over all pixels; y bf16 [...,C].  With a workspace
+    (ops.bn_workspace) the reduction is ordered: the same bits on every run."""
+    _need_cuda(y, sums, workspace)
     M, C = _map2d(y, "bn_stats y")
     _vec_f32(sums, 2 * C, "bn_stats: sums")
+    _check_bn_ws(workspace)
     with _Span("bn_stats", 0, M * C * 2):
-        check(_lib.load().rvit_bn_stats(y.data_ptr(), M, C, sums.data_ptr(), _stream()), "rvit_bn_stats")
+        check(_lib.load().rvit_bn_stats(y.data_ptr(), M, C, sums.data_ptr(), _ptr(workspace), _stream()), "rvit_bn_stats")
     return sums
 
 
@@ -730,10 +745,12 @@ def _check_relu_mask(mask, M, C, relu):
 def bn_bwd(dz: torch.Tensor, z: Optional[torch.Tensor], y: torch.Tensor, fwd_sums: torch.Tensor,
            bwd_sums: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, *,
            eps: float, relu: bool, dz_masked: Optional[torch.Tensor] = None,
-           relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+           relu_mask: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Both BatchNorm backward passes (reduce, then apply); bwd_sums must be zero on entry.  With relu the sign of
-    the forward output comes from `relu_mask` (the bits `bn_apply` wrote) when given, else from z."""
-    _need_cuda(dz, z, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, dz_masked, relu_mask)
+    the forward output comes from `relu_mask` (the bits `bn_apply` wrote) when given, else from z.  workspace
+    (ops.bn_workspace): ordered reduction, as in bn_stats."""
+    _need_cuda(dz, z, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, dz_masked, relu_mask, workspace)
+    _check_bn_ws(workspace)
     M, C = _map2d(y, "bn_bwd y")
     _check_relu_mask(relu_mask, M, C, relu)
     for t in (dz, dy, z, dz_masked):
@@ -747,7 +764,7 @@ def bn_bwd(dz: torch.Tensor, z: Optional[torch.Tensor], y: torch.Tensor, fwd_sum
     lib = _lib.load()
     with _Span("bn_bwd_reduce", 0, _nbytes(dz, y, z if relu else None)):
         check(lib.rvit_bn_bwd_reduce(dz.data_ptr(), _ptr(zsrc), y.data_ptr(), fwd_sums.data_ptr(), M, C, eps, mode,
-                                     bwd_sums.data_ptr(), _stream()), "rvit_bn_bwd_reduce")
+                                     bwd_sums.data_ptr(), _ptr(workspace), _stream()), "rvit_bn_bwd_reduce")
     with _Span("bn_bwd_apply", 0, _nbytes(dz, y, zsrc if relu else None, dy, dz_masked)):
         check(lib.rvit_bn_bwd_apply(dz.data_ptr(), _ptr(zsrc), y.data_ptr(), fwd_sums.data_ptr(), bwd_sums.data_ptr(),
                                     gamma.data_ptr(), dy.data_ptr(), _ptr(dz_masked), dgamma.data_ptr(),

@@ -227,6 +227,11 @@ class TrainEngine:
         self._bufs: Dict[int, dict] = {}
         self.reducer = None
         self.last_flat = None
+        # BatchNorm batch statistics and their backward sums by ordered reductions (same bits on every run): what
+        # torch.backends.cudnn.deterministic asks of the reference (train_vit.py:50).  RVIT_BN_ORDERED=0 selects the
+        # float-atomic form (a few percent faster on the small maps, last bits vary).
+        import os
+        self.ordered_bn = os.environ.get("RVIT_BN_ORDERED", "1") != "0"
 
     # ---- data parallel -------------------------------------------------------------------------
     def set_data_parallel(self, process_group=None, bucket_mb: float = 8.0) -> None:
@@ -335,6 +340,7 @@ class TrainEngine:
             b["blocks"] = blocks
             b["fsums"] = torch.zeros(nsum, **f)
             b["bsums"] = torch.zeros(nsum, **f)
+            b["bn_ws"] = ops.bn_workspace(dev)
             # scratch maps for the stem backward, sized per stage on demand
             b["scratch"] = {}
         else:
@@ -377,9 +383,10 @@ class TrainEngine:
     def _bn_params(self, bn):
         return bn.weight.detach(), bn.bias.detach()
 
-    def _conv_bn(self, x, w, y, z, bn, fs, *, kh, stride, pad, relu, residual=None, seg_len=None, kw=None, mask=None):
+    def _conv_bn(self, x, w, y, z, bn, fs, *, kh, stride, pad, relu, residual=None, seg_len=None, kw=None, mask=None,
+                 ws=None):
         ops.conv2d(x, w, y, kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, seg_len=seg_len)
-        ops.bn_stats(y, fs)
+        ops.bn_stats(y, fs, ws)
         ops.bn_apply(y, fs, bn.weight.detach(), bn.bias.detach(), z, eps=bn.eps, relu=relu, residual=residual,
                      momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, relu_mask=mask)
         bn.num_batches_tracked += 1
@@ -389,10 +396,11 @@ class TrainEngine:
         b["fsums"].zero_()
         off = 0
         fs = b["fsums"]
+        ws = b["bn_ws"] if self.ordered_bn else None
         # stem entry: conv 7x7/2, then BatchNorm + ReLU + max-pool in one pass (the normalised 112x112 map is not
         # written: the backward pass needs only its sign bits and the argmax taps)
         ops.conv2d(b["img"], P["conv1_w"], b["c1_y"], kh=7, kw=1, stride=2, pad=0, seg_len=32)
-        ops.bn_stats(b["c1_y"], fs[off:off + 128])
+        ops.bn_stats(b["c1_y"], fs[off:off + 128], ws)
         ops.bn_apply_pool(b["c1_y"], fs[off:off + 128], cb.bn1.weight.detach(), cb.bn1.bias.detach(), b["pool"],
                           b["pool_arg"], b["c1_m"], eps=cb.bn1.eps, momentum=cb.bn1.momentum,
                           running_mean=cb.bn1.running_mean, running_var=cb.bn1.running_var)
@@ -404,15 +412,15 @@ class TrainEngine:
             d["in"] = cur
             d["fs_off"] = off
             self._conv_bn(cur, pk["c1_w"], d["y1"], d["z1"], blk.bn1, fs[off:off + 2 * co], kh=3, stride=s, pad=1,
-                          relu=True, mask=d["m1"])
+                          relu=True, mask=d["m1"], ws=ws)
             off += 2 * co
             idn = cur
             if "ds_w" in pk:
                 self._conv_bn(cur, pk["ds_w"], d["yd"], d["zd"], blk.downsample["1"], fs[off + 2 * co:off + 4 * co],
-                              kh=1, stride=s, pad=0, relu=False)
+                              kh=1, stride=s, pad=0, relu=False, ws=ws)
                 idn = d["zd"]
             self._conv_bn(d["z1"], pk["c2_w"], d["y2"], d["zo"], blk.bn2, fs[off:off + 2 * co], kh=3, stride=1, pad=1,
-                          relu=True, residual=idn, mask=d["mo"])
+                          relu=True, residual=idn, mask=d["mo"], ws=ws)
             off += 2 * co * (2 if "ds_w" in pk else 1)
             cur = d["zo"]
         return cur
@@ -487,6 +495,7 @@ class TrainEngine:
         cb = self.m.cnn_backbone
         b["bsums"].zero_()
         bs_all, fs_all = b["bsums"], b["fsums"]
+        ws = b["bn_ws"] if self.ordered_bn else None
         dz = dfeat
         blocks = list(zip(list(cb.blocks()), P["blocks"], b["blocks"],
                           [n for n in self._block_names()]))
@@ -503,7 +512,7 @@ class TrainEngine:
             dzm = self._scratch(b, ("dzm", co, d["y2"].shape[1]), d["y2"])
             ops.bn_bwd(dz, None, d["y2"], f2, b2, blk.bn2.weight.detach(), dy2,
                        self._g(flat, pref + "bn2.weight"), self._g(flat, pref + "bn2.bias"), eps=blk.bn2.eps, relu=True,
-                       dz_masked=dzm, relu_mask=d["mo"])
+                       dz_masked=dzm, relu_mask=d["mo"], workspace=ws)
             ops.conv2d_wgrad(dy2, d["z1"], self._g(flat, pref + "conv2.weight").view(co, 9 * co), kh=3, kw=3, stride=1,
                              pad=1)
             dz1 = self._scratch(b, ("dz1", co, d["y2"].shape[1]), d["y2"])
@@ -511,7 +520,7 @@ class TrainEngine:
             dy1 = dy2  # dy2 is dead now
             ops.bn_bwd(dz1, None, d["y1"], f1, b1, blk.bn1.weight.detach(), dy1,
                        self._g(flat, pref + "bn1.weight"), self._g(flat, pref + "bn1.bias"), eps=blk.bn1.eps, relu=True,
-                       relu_mask=d["m1"])
+                       relu_mask=d["m1"], workspace=ws)
             xin = d["in"]
             ops.conv2d_wgrad(dy1, xin, self._g(flat, pref + "conv1.weight").view(co, 9 * ci), kh=3, kw=3, stride=s,
                              pad=1)
@@ -520,7 +529,7 @@ class TrainEngine:
                 dyd = dz1  # dz1 is dead now
                 ops.bn_bwd(dzm, None, d["yd"], fd, bd, blk.downsample["1"].weight.detach(), dyd,
                            self._g(flat, pref + "downsample.1.weight"), self._g(flat, pref + "downsample.1.bias"),
-                           eps=blk.downsample["1"].eps, relu=False)
+                           eps=blk.downsample["1"].eps, relu=False, workspace=ws)
                 ops.conv2d_wgrad(dyd, xin, self._g(flat, pref + "downsample.0.weight").view(co, ci), kh=1, kw=1,
                                  stride=s, pad=0)
                 if s == 2:
@@ -542,7 +551,7 @@ class TrainEngine:
         dyc = self._scratch(b, ("dyc",), b["c1_y"])
         ops.bn_bwd(dc1, None, b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(), dyc,
                    self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"), eps=cb.bn1.eps,
-                   relu=True, relu_mask=b["c1_m"])
+                   relu=True, relu_mask=b["c1_m"], workspace=ws)
         dw1 = torch.zeros(64, 224, dtype=F32, device=dyc.device)
         ops.conv2d_wgrad(dyc, b["img"], dw1, kh=7, kw=1, stride=2, pad=0, seg_len=32)
         self._g(flat, "cnn_backbone.conv1.weight").view(64, 7, 7, 3).copy_(dw1.view(64, 7, 8, 4)[:, :, :7, :3])
