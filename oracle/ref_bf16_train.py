@@ -34,3 +34,37 @@ def attach_bf16_rounding(ref: CNNViTHybridRef) -> list:
         if isinstance(mod, (nn.Conv2d, nn.BatchNorm2d, _BasicBlock)):
             hooks.append(mod.register_forward_hook(lambda m, i, o: _RoundSTE.apply(o)))
     return hooks
+
+
+def emulate_hip_training_storage(ref: CNNViTHybridRef) -> None:
+    """The fp32 oracle turned into an emulation of WHERE the HIP training path (vit_amd/trainer.py) stores bf16:
+      * every conv / Linear weight is the bf16-rounded master weight (the operand copies of WeightMirror /
+        _TorchPacker); gradients are taken at those rounded weights, as the kernels do;
+      * the input image is bf16 (rvit_input_pack_nhwc4);
+      * stem maps written to HBM are bf16, and so are their gradients: conv outputs `y`, BatchNorm(+ReLU) outputs
+        `z1` / `zd`, block outputs `zo`.  bn2's output is NOT rounded on its own: rvit_bn_apply adds the residual
+        and applies the ReLU in fp32 and rounds once (the block-output hook).
+    The encoder keeps fp32 activations here (its bf16 storage moves gradients by < 3 %, tests/test_train_gpu.py)."""
+    with torch.no_grad():
+        for mod in ref.modules():
+            if isinstance(mod, (nn.Conv2d, nn.Linear)):
+                mod.weight.copy_(mod.weight.to(torch.bfloat16).float())
+            if isinstance(mod, nn.MultiheadAttention):
+                mod.in_proj_weight.copy_(mod.in_proj_weight.to(torch.bfloat16).float())
+    if ref.cnn_backbone is None:
+        ref.patch_embed.register_forward_pre_hook(lambda m, i: (_RoundSTE.apply(i[0]),))
+        return
+    cb = ref.cnn_backbone
+    cb.register_forward_pre_hook(lambda m, i: (_RoundSTE.apply(i[0]),))
+    rnd = lambda m, i, o: _RoundSTE.apply(o)  # noqa: E731
+    cb.conv1.register_forward_hook(rnd)
+    cb.bn1.register_forward_hook(rnd)
+    for mod in cb.modules():
+        if isinstance(mod, _BasicBlock):
+            mod.conv1.register_forward_hook(rnd)
+            mod.bn1.register_forward_hook(rnd)
+            mod.conv2.register_forward_hook(rnd)
+            if mod.downsample is not None:
+                mod.downsample[0].register_forward_hook(rnd)
+                mod.downsample[1].register_forward_hook(rnd)
+            mod.register_forward_hook(rnd)

@@ -10,6 +10,14 @@
                          identical on every box): eval logits, train-mode loss, per-parameter gradient
                          L2 norms, and the logits of the 11 images
 
+  fitted_head_{R,P}.npz  (python scripts/make_golden.py fitted)  head.0 / head.3 weights fitted on the CPU (AdamW on the
+  fitted_vectors_*.npz   oracle's fp32 cls features, everything below the head stays the seed-0 synthetic checkpoint)
+                         so that the ORACLE's predictions cover all 11 classes: image i -> class i on the 11 real
+                         spectrograms, synthetic frame j (micro_doppler_batch(33, seed=4242)) -> class j % 11, with
+                         top-1 margins > 4 against a bf16 logit error of ~0.2.  With the plain synthetic weights every
+                         input predicts one class and an argmax assertion cannot fail.  The vectors hold the
+                         oracle's logits on the 11 images, the 33 fitted frames and 16 held-out frames (seed 777).
+
 The reference itself cannot be imported (timm / torchvision absent: ModuleNotFoundError), so these
 pin the ORACLE across machines and torch builds; they are not outputs of the reference's code.
 """
@@ -82,5 +90,63 @@ def main():
     print("image top-1 margins:", np.round(srt[:, -1] - srt[:, -2], 2))
 
 
+# fitted fixtures: name -> (model config, synthetic seed of everything below the head)
+FITTED = {
+    "R": (dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.0, backbone="resnet18"), 0),
+    # BASELINE configs[0]: the pure-ViT `vit_radar.pt` layout (build-defined, backbone='patch16')
+    "P": (dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.0, backbone="patch16"), 5),
+}
+HEAD_KEYS = ("head.0.weight", "head.0.bias", "head.3.weight", "head.3.bias")
+
+
+def make_fitted(name):
+    """Fits the classifier head of a synthetic checkpoint on the oracle's own features (CPU) and records the oracle's
+    logits with it.  Only the head (34k floats) is committed; the other weights regenerate from the seed."""
+    import torch.nn as nn
+    torch.set_num_threads(8)
+    cfg, seed = FITTED[name]
+    ref = CNNViTHybridRef(**cfg)
+    sd = synth_state_dict({k: v.shape for k, v in ref.state_dict().items()}, seed)
+    ref.load_state_dict(sd)
+    ref.eval()
+    ximg = torch.stack([preprocess(Image.open(os.path.join(GOLD, "images", c + ".png"))) for c in CLASSES])
+    xfit = micro_doppler_batch(33, seed=4242)
+    xheld = micro_doppler_batch(16, seed=777)
+    y = torch.cat([torch.arange(11), torch.arange(33) % 11])
+    with torch.no_grad():
+        f = ref.forward_features(torch.cat([ximg, xfit]))
+    torch.manual_seed(0)
+    E = cfg["embed_dim"]
+    head = nn.Sequential(nn.Linear(E, E // 2), nn.GELU(), nn.Dropout(0.0), nn.Linear(E // 2, 11))   # train_vit.py:122-127
+    for m in head:
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            nn.init.zeros_(m.bias)
+    opt = torch.optim.AdamW(head.parameters(), lr=3e-3, weight_decay=0.05)
+    for _ in range(400):
+        opt.zero_grad()
+        # feature noise of the size of the bf16 storage error: the margins must survive it
+        F.cross_entropy(head(f + 0.03 * torch.randn_like(f)), y, label_smoothing=0.05).backward()
+        opt.step()
+    fitted = {"head.0.weight": head[0].weight, "head.0.bias": head[0].bias, "head.3.weight": head[3].weight,
+              "head.3.bias": head[3].bias}
+    fitted = {k: v.detach().clone() for k, v in fitted.items()}
+    np.savez_compressed(os.path.join(GOLD, f"fitted_head_{name}.npz"), **{k: v.numpy() for k, v in fitted.items()})
+    sd.update(fitted)
+    ref.load_state_dict(sd)
+    with torch.no_grad():
+        out = {"image_logits": ref(ximg).numpy(), "fit_logits": ref(xfit).numpy(), "heldout_logits": ref(xheld).numpy()}
+    np.savez_compressed(os.path.join(GOLD, f"fitted_vectors_{name}.npz"), **out)
+    for k, v in out.items():
+        srt = np.sort(v, axis=1)
+        print(name, k, "argmax", v.argmax(1).tolist(), "min margin %.2f" % (srt[:, -1] - srt[:, -2]).min())
+    assert out["image_logits"].argmax(1).tolist() == list(range(11))
+    assert out["fit_logits"].argmax(1).tolist() == [j % 11 for j in range(33)]
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "fitted":
+        for nm in FITTED:
+            make_fitted(nm)
+    else:
+        main()

@@ -91,3 +91,30 @@ def test_load_model_errors(tmp_path):
     corrupt.write_bytes(b"not a png")
     ok, msg = validate_input(str(corrupt))
     assert not ok and "Corrupted" in msg
+
+
+@pytest.mark.parametrize("name", ["R", "P"])
+def test_oracle_reproduces_fitted_vectors_and_they_are_diverse(name):
+    """The fitted fixtures (tests/fitted.py): the oracle reproduces the committed logits, and its predictions cover
+    ALL 11 classes with real margins - the argmax checks of the GPU tests can fail (with the plain
+    synthetic weights every input predicted one class)."""
+    from oracle.ref_model import CNNViTHybridRef
+    from tests.fitted import FITTED, fitted_inputs, fitted_state_dict, fitted_vectors
+    cfg, _ = FITTED[name]
+    ref = CNNViTHybridRef(**cfg)
+    ref.load_state_dict(fitted_state_dict(name, {k: v.shape for k, v in ref.state_dict().items()}))
+    ref.eval()
+    vec = fitted_vectors(name)
+    ximg, xfit, xheld = fitted_inputs()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        got = {"image_logits": ref(ximg).numpy(), "fit_logits": ref(xfit[:11]).numpy(), "heldout_logits": ref(xheld[:8]).numpy()}
+    assert np.allclose(got["image_logits"], vec["image_logits"], rtol=1e-3, atol=3e-3)
+    assert np.allclose(got["fit_logits"], vec["fit_logits"][:11], rtol=1e-3, atol=3e-3)
+    assert np.allclose(got["heldout_logits"], vec["heldout_logits"][:8], rtol=1e-3, atol=3e-3)
+    assert vec["image_logits"].argmax(1).tolist() == list(range(11))
+    assert vec["fit_logits"].argmax(1).tolist() == [j % 11 for j in range(33)]
+    assert len(set(vec["heldout_logits"].argmax(1).tolist())) >= 6
+    for k in ("image_logits", "fit_logits"):
+        srt = np.sort(vec[k], axis=1)
+        assert (srt[:, -1] - srt[:, -2]).min() > 3.0

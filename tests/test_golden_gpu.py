@@ -90,3 +90,59 @@ def test_real_images_to_labels(dev, tmp_path):
     assert len(predict_batch(model, mixed, classes, dev, device_preprocess=True)) == 2
     folder_dev = predict_folder(model, os.path.join(GOLD, "images"), classes, dev, device_preprocess=True)
     assert {k: v.prediction for k, v in folder_dev.items()} == {k: v.prediction for k, v in folder.items()}
+
+
+# Fixed logit bounds for the fitted fixtures: 1.5 x the largest |HIP - fp32 oracle| measured on the round-2 tree
+# (printed by the test: "measured / bound").  bf16 storage through 20 conv layers + 4 encoder layers (R) / the 16x16
+# patch conv + 4 encoder layers (P); logits of magnitude ~5.
+FITTED_BOUND = {"R": 0.31, "P": 0.46}   # measured 0.203 / 0.307
+
+
+@pytest.mark.parametrize("name", ["R", "P"])
+def test_fitted_checkpoint_labels_agree_exactly(dev, tmp_path, name):
+    """BASELINE configs[0] / configs[1] as written: a checkpoint file in the reference layout (`cnn_vit_radar.pt`:
+    hybrid; `vit_radar.pt`: the pure-ViT patch16 layout) -> load_model -> the 11 spectrogram files -> labels
+    (infer.py:268-406).  The checkpoint's head is fitted so that the oracle predicts class i for image i and class
+    j % 11 for synthetic frame j with margins > 4: the HIP path must reproduce EVERY label (an input-independent path
+    would get 1 of 11), and the logits within the fixed bound."""
+    from PIL import Image
+    from tests.fitted import FITTED, fitted_inputs, fitted_state_dict, fitted_vectors
+    from vit_amd.infer import load_model, predict_batch, predict_folder
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.synth import CLASSES, synth_checkpoint
+    cfg, seed = FITTED[name]
+    proto = CNNViTHybrid(**cfg)
+    ck = synth_checkpoint(proto, seed=seed)
+    ck["model"] = fitted_state_dict(name, {k: v.shape for k, v in proto.state_dict().items()})
+    assert ck["model_config"]["backbone"] == cfg["backbone"]
+    path = tmp_path / ("cnn_vit_radar.pt" if name == "R" else "vit_radar.pt")
+    torch.save(ck, path)
+    model, classes, meta = load_model(str(path), dev)
+    assert classes == CLASSES and not model.training
+    assert (model.cnn_backbone is None) == (name == "P")
+    vec = fitted_vectors(name)
+    bound = FITTED_BOUND[name]
+    # (1) files -> labels through the reference-shaped callers
+    imgs = [Image.open(os.path.join(GOLD, "images", c + ".png")) for c in CLASSES]
+    res = predict_batch(model, imgs, classes, dev, top_k=3)
+    assert [r.prediction for r in res] == CLASSES
+    folder = predict_folder(model, os.path.join(GOLD, "images"), classes, dev)
+    assert all(folder[c + ".png"].prediction == c for c in CLASSES)
+    got_img = np.concatenate([r.raw_logits for r in res])
+    # (2) the synthetic frames, fitted and held out
+    ximg, xfit, xheld = fitted_inputs()
+    with torch.no_grad():
+        got_fit = model(xfit.to(dev)).cpu().numpy()
+        got_held = model(xheld.to(dev)).cpu().numpy()
+    assert got_fit.argmax(1).tolist() == [j % 11 for j in range(33)]
+    worst = 0.0
+    for got, key in ((got_img, "image_logits"), (got_fit, "fit_logits"), (got_held, "heldout_logits")):
+        ref = vec[key]
+        err = np.abs(got - ref).max()
+        worst = max(worst, err)
+        srt = np.sort(ref, axis=1)
+        decided = (srt[:, -1] - srt[:, -2]) > 2 * bound
+        assert (got.argmax(1) == ref.argmax(1))[decided].all(), key
+    print(f"\n[fitted {name}] max |logit - oracle| measured {worst:.4f} / bound {bound}")
+    assert worst <= bound
+    assert len(set(got_held.argmax(1).tolist())) >= 6 and len(set(got_img.argmax(1).tolist())) == 11

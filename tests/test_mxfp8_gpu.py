@@ -121,6 +121,8 @@ MODEL_CASES = [
     ("vit-E256-L4", dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="patch16"), 5),
     ("R-hybrid", dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18"), 4),
     ("vit-E768-L3", dict(num_classes=11, embed_dim=768, num_heads=12, num_layers=3, dropout=0.1, backbone="patch16"), 2),
+    # BASELINE configs[4] at its own width: ViT-L/16-scale layers (E1024 / H16), two of the 24
+    ("vit-L-scale-E1024-H16-L2", dict(num_classes=11, embed_dim=1024, num_heads=16, num_layers=2, dropout=0.1, backbone="patch16"), 2),
 ]
 
 

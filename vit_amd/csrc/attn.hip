@@ -172,15 +172,8 @@ int launch_attn_fwd(const bf16* qkv, bf16* out, float* lse, int B, int S, int H,
                     DropKey dk, hipStream_t st) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int LDS = PAIRS * 32 * NKB * (128 + V_PITCH);
-  static bool attr_set = false;
-  if (LDS > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      rvit_set_error("attn_fwd: cannot raise LDS limit to %d: %s", LDS, hipGetErrorString(e));
-      return RVIT_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)attn_fwd_kernel<NKB>}, LDS, "attn_fwd")) return rc;
   const int total = B * H;
   const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
   hipLaunchKernelGGL((attn_fwd_kernel<NKB>), dim3(grid), dim3(256), LDS, st, qkv, out, lse, total, S, H, ldq, ldo,
@@ -451,15 +444,8 @@ int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float*
                     long ldq, long ldo, long lddo, long lddq, float scale, DropKey dk, hipStream_t st) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int LDS = PAIRS * (4 * 32 * NKB * 128 + 32 * NKB * 8);
-  static bool attr_set = false;
-  if (LDS > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      rvit_set_error("attn_bwd: cannot raise LDS limit to %d: %s", LDS, hipGetErrorString(e));
-      return RVIT_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)attn_bwd_kernel<NKB>}, LDS, "attn_bwd")) return rc;
   const int total = B * H;
   const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
   hipLaunchKernelGGL((attn_bwd_kernel<NKB>), dim3(grid), dim3(64 * bwd_waves<NKB>()), LDS, st, qkv, O, dO, lse, dqkv, total, S, H, ldq,

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <initializer_list>
+#include <mutex>
+
 typedef __bf16 bf16;
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -33,6 +37,38 @@ void rvit_set_error(const char* fmt, ...);
   } while (0)
 
 static inline bool rvit_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Raising hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: a launcher keeps one of
+// these (function-local static: initialised thread-safely) and calls ensure() before every launch.  The fast path is
+// one hipGetDevice and one atomic load; the attribute is set under a mutex the first time a device (or a larger
+// size) is seen, so the library stays re-entrant across threads and correct on every GPU of the process.
+constexpr int RVIT_MAX_DEVICES = 64;
+struct RvitLdsLimit {
+  std::atomic<int> have[RVIT_MAX_DEVICES];
+  std::mutex mu;
+  RvitLdsLimit() { for (auto& h : have) h.store(0, std::memory_order_relaxed); }
+  int ensure(std::initializer_list<const void*> kernels, int bytes, const char* what) {
+    if (bytes <= 65536) return RVIT_OK;   // the default limit
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RVIT_MAX_DEVICES) {
+      rvit_set_error("%s: no current device (index %d)", what, dev);
+      return RVIT_ELAUNCH;
+    }
+    if (have[dev].load(std::memory_order_acquire) >= bytes) return RVIT_OK;
+    std::lock_guard<std::mutex> lk(mu);
+    if (have[dev].load(std::memory_order_relaxed) >= bytes) return RVIT_OK;
+    for (const void* k : kernels) {
+      const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      if (e != hipSuccess) {
+        rvit_set_error("%s: cannot raise the dynamic LDS limit to %d bytes on device %d: %s", what, bytes, dev,
+                       hipGetErrorString(e));
+        return RVIT_ELAUNCH;
+      }
+    }
+    have[dev].store(bytes, std::memory_order_release);
+    return RVIT_OK;
+  }
+};
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -175,15 +175,8 @@ int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale
                  "stem_conv1_pool: operands must be 16-byte aligned");
   RVIT_CHECK_ARG((long)B * (HQ / TP) < 0x7fffffffL, "stem_conv1_pool: batch too large");
   static_assert(CO_BYTES >= W_BYTES + PATCH_BYTES, "conv-out map must cover the staging area it aliases");
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv1_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CO_BYTES);
-    if (e != hipSuccess) {
-      rvit_set_error("stem_conv1_pool: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return RVIT_ELAUNCH;
-    }
-    attr = true;
-  }
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)conv1_pool_kernel}, CO_BYTES, "stem_conv1_pool")) return rc;
   hipLaunchKernelGGL(conv1_pool_kernel, dim3((unsigned)(B * (HQ / TP))), dim3(512), CO_BYTES, st, (const bf16*)img,
                      (const bf16*)w, scale, bias, (bf16*)pooled, relu);
   RVIT_CHECK_LAUNCH("stem_conv1_pool");

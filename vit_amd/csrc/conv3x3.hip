@@ -345,15 +345,8 @@ static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream
   int lds = (DB ? 2 : 1) * patch_bytes + 2 * BN * 128;
   const int ep = (C3_WAVES == 16 ? 16 * 16 : C3_BM * (BN / 64)) * (64 * 4 + 16);   // wave-private epilogue staging, all waves
   if (lds < ep) lds = ep;
-  static int attr_lds = 0;
-  if (lds > 65536 && lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_direct_kernel<BN, DB, C3_WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      rvit_set_error("conv3x3: cannot raise the dynamic LDS limit to %d bytes: %s", lds, hipGetErrorString(e));
-      return RVIT_ELAUNCH;
-    }
-    attr_lds = lds;
-  }
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)conv3x3_direct_kernel<BN, DB, C3_WAVES>}, lds, "conv3x3")) return rc;
   const long tiles = ((a.M + tile_len - 1) / tile_len) * (long)(a.N / BN);
   if (tiles <= 0) return RVIT_OK;
   RVIT_CHECK_ARG(tiles < 0x7fffffffL, "conv3x3: too many tiles");

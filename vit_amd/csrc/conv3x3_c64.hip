@@ -266,15 +266,8 @@ bool rvit_conv3x3_c64_ok(const GemmArgs& a) {
 
 template <bool HAS_R, bool RELU, bool AFFINE>
 static int c64_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<HAS_R, RELU, AFFINE>, hipFuncAttributeMaxDynamicSharedMemorySize, L1_LDS);
-    if (e != hipSuccess) {
-      rvit_set_error("conv3x3_c64: cannot raise the dynamic LDS limit to %d bytes: %s", L1_LDS, hipGetErrorString(e));
-      return RVIT_ELAUNCH;
-    }
-    attr_set = true;
-  }
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)conv3x3_c64_kernel<HAS_R, RELU, AFFINE>}, L1_LDS, "conv3x3_c64")) return rc;
   const long ntiles = a.M / L1_TILE;
   const int grid = (int)(ntiles < n_cu ? ntiles : n_cu);
   hipLaunchKernelGGL((conv3x3_c64_kernel<HAS_R, RELU, AFFINE>), dim3(grid), dim3(64 * L1_WAVES), L1_LDS, st, a, (int)ntiles, a.H / L1_ROWS);

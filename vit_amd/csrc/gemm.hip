@@ -13,9 +13,10 @@
 //
 // Structure (gfx950): 2/4/8 waves, each owning a 32x64 slice of a {64,128,256}x64 output tile (large products: sixteen
 // waves of 64x64 on a 256x256 tile), BK=64.  Operand tiles go
-// global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into a 3-deep ring: tile
-// kt+2 is issued while tile kt is consumed, the wave waits with a COUNTED vmcnt so that one tile
-// stays in flight across the single raw s_barrier per K tile.  LDS rows are 128 B; the 16-byte
+// global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into a 2-stage ring (every instantiation
+// below has STAGES = 2; a 3-deep ring was measured in round 1 and cost more in occupancy than it hid): tile
+// kt+1 is issued right after the barrier that frees its stage while tile kt is consumed, and the wave waits with a
+// COUNTED vmcnt so that the newer tile stays in flight across the single raw s_barrier per K tile.  LDS rows are 128 B; the 16-byte
 // chunk index is XOR-swizzled with (row>>1)&7 — applied on the per-lane SOURCE address (the DMA
 // destination is lane-linear) and again on the ds_read_b128 fragment reads, which makes every
 // fragment read bank-conflict free.  v_mfma_f32_16x16x32_bf16 with the operands swapped (weights
@@ -280,18 +281,10 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return RVIT_EINVAL;
   }
   constexpr int lds = STAGES * (BM + BN) * 128;
-  static bool attr_done = false;
-  if (lds > 65536 && !attr_done) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-      rvit_set_error("gemm: cannot raise the dynamic LDS limit to %d bytes", lds);
-      return RVIT_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, true>,
+                                 (const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, false>}, lds, "gemm"))
+    return rc;
   if (a.mode == 1)
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, true>), dim3((unsigned)tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
   else

@@ -315,15 +315,8 @@ int rvit_gemm_mxfp8_dispatch(const MxGemmArgs& a, hipStream_t st) {
   const long tiles = ((a.M + MX_BM - 1) / MX_BM) * (long)((a.N + MX_BN - 1) / MX_BN);
   RVIT_CHECK_ARG(tiles < 0x7fffffffL, "gemm_mxfp8: too many tiles");
   constexpr int lds = 2 * MX_TILE_BYTES;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      rvit_set_error("gemm_mxfp8: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-      return RVIT_ELAUNCH;
-    }
-    attr = true;
-  }
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)gemm_mxfp8_kernel}, lds, "gemm_mxfp8")) return rc;
   hipLaunchKernelGGL(gemm_mxfp8_kernel, dim3((unsigned)tiles), dim3(64 * MX_WAVES), lds, st, a);
   RVIT_CHECK_LAUNCH("gemm_mxfp8");
   return RVIT_OK;

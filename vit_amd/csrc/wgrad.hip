@@ -316,15 +316,9 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
     if (a.splits == -3 || pays) {
       RVIT_CHECK_ARG(tiles16 * sp < 0x7fffffffL, "wgrad: too many workgroups");
       const size_t lds16 = 2 * 4 * TILE_B;  // 128 KB
-      static bool attr16 = false;
-      if (!attr16) {
-        if (hipFuncSetAttribute((const void*)wgrad_bf16_kernel<false, false, false, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16) != hipSuccess) {
-          rvit_set_error("wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds16);
-          return RVIT_ELAUNCH;
-        }
-        attr16 = true;
-      }
+      static RvitLdsLimit lim16;
+      if (const int rc = lim16.ensure({(const void*)wgrad_bf16_kernel<false, false, false, true>}, (int)lds16, "wgrad(w16)"))
+        return rc;
       hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, false, true>), dim3((unsigned)(tiles16 * sp)), dim3(1024), lds16, st, a,
                          (int)tiles16, (int)sp);
       RVIT_CHECK_LAUNCH("wgrad_bf16");
@@ -351,16 +345,10 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
   if (!narrow && w8) {
     // eight waves: the wave-private epilogue staging (8 x 32 rows x 272 B) is what sizes the LDS
     const size_t lds8 = 8 * 32 * (64 * 4 + 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e1 = hipFuncSetAttribute((const void*)wgrad_bf16_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-      hipError_t e2 = hipFuncSetAttribute((const void*)wgrad_bf16_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-      if (e1 != hipSuccess || e2 != hipSuccess) {
-        rvit_set_error("wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds8);
-        return RVIT_ELAUNCH;
-      }
-      attr_set = true;
-    }
+    static RvitLdsLimit lim8;
+    if (const int rc = lim8.ensure({(const void*)wgrad_bf16_kernel<true, false, true>,
+                                    (const void*)wgrad_bf16_kernel<false, false, true>}, (int)lds8, "wgrad(w8)"))
+      return rc;
     if (a.mode == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, true>), grid, dim3(512), lds8, st, a, (int)tiles, (int)splits);
     else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, true>), grid, dim3(512), lds8, st, a, (int)tiles, (int)splits);
   } else if (a.mode == 1) {

@@ -330,17 +330,10 @@ int rvit_conv3x3_wgrad_direct(const WgradArgs& a, hipStream_t st) {
   p.nsplits = splits;
   p.patch_bytes = ((w3_patch_pixels(a.H, a.W, p.tile_len) + 7) / 8) * 1024;
   const int lds = WD_STAGES * (p.patch_bytes + WD_TL * 128) + 1024;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)conv3x3_wgrad_direct_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      rvit_set_error("conv3x3 wgrad: cannot raise the dynamic LDS limit to %d bytes: %s", lds, hipGetErrorString(e));
-      return RVIT_ELAUNCH;
-    }
-    attr_lds = lds;
-  }
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)conv3x3_wgrad_direct_kernel<true>, (const void*)conv3x3_wgrad_direct_kernel<false>},
+                                lds, "conv3x3 wgrad"))
+    return rc;
   const bool aligned = a.W >= 14 && p.tile_len % a.W == 0 && a.H % (p.tile_len / a.W) == 0;
   if (aligned) hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel<true>, dim3((unsigned)(pairs * splits)), dim3(64 * WD_WAVES), lds, st, p);
   else hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel<false>, dim3((unsigned)(pairs * splits)), dim3(64 * WD_WAVES), lds, st, p);

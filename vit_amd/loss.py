@@ -15,7 +15,8 @@ class _CrossEntropy(torch.autograd.Function):
         lg = logits.detach().float().contiguous()
         loss = torch.zeros(1, dtype=torch.float32, device=lg.device)
         dl = torch.empty_like(lg)
-        ops.ce_loss(lg, target.contiguous(), loss, dl, None, label_smoothing, grad_scale=1.0 / lg.shape[0])
+        with torch.cuda.device(lg.device):
+            ops.ce_loss(lg, target.contiguous(), loss, dl, None, label_smoothing, grad_scale=1.0 / lg.shape[0])
         ctx.save_for_backward(dl)
         return loss[0]
 

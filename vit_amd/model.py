@@ -284,6 +284,15 @@ class CNNViTHybrid(nn.Module):
             if self.training and self.cnn_backbone is not None:
                 raise ValueError("Expected more than 1 value per channel when training, got an empty batch")
             return x.new_zeros((0, self.embed_dim if features_only else self.num_classes), dtype=torch.float32)
+        if self.pos_embed.device != x.device:
+            raise RuntimeError(f"input on {x.device} but the model's parameters on {self.pos_embed.device}")
+        # librvit launches on the CURRENT device's stream: make the tensors' device current for the whole forward
+        # (a model on cuda:1 called while cuda:0 is current would otherwise launch on device 0 against device-1
+        # pointers); a no-op when it already is
+        with torch.cuda.device(x.device):
+            return self._run_on_device(x, features_only)
+
+    def _run_on_device(self, x, features_only: bool):
         if self.training:
             # train(): BatchNorm batch statistics; backward on librvit when gradients are recorded.
             # A training forward means the weights are about to change: the inference engine re-packs next time

@@ -86,14 +86,15 @@ class FusedAdamW(torch.optim.Optimizer):
         grp = self.param_groups[0]
         self._step += 1
         norm = None
-        if self.max_grad_norm is not None:
-            self._norm_sq.zero_()
-            norm = ops.sumsq(flat_g, self._norm_sq)
-        b1, b2 = grp["betas"]
-        ops.adamw_step(self.flat_params, flat_g, self.exp_avg, self.exp_avg_sq, lr=grp["lr"], beta1=b1, beta2=b2,
-                       eps=grp["eps"], weight_decay=grp["weight_decay"], step=self._step, grad_norm_sq=norm,
-                       max_grad_norm=float(self.max_grad_norm or 0.0), params_bf16=self.mirror.bf16)
-        self.mirror.refresh(full=False)      # K-major copies for the backward GEMMs: one batched-transpose launch
+        with torch.cuda.device(self.flat_params.device):
+            if self.max_grad_norm is not None:
+                self._norm_sq.zero_()
+                norm = ops.sumsq(flat_g, self._norm_sq)
+            b1, b2 = grp["betas"]
+            ops.adamw_step(self.flat_params, flat_g, self.exp_avg, self.exp_avg_sq, lr=grp["lr"], beta1=b1, beta2=b2,
+                           eps=grp["eps"], weight_decay=grp["weight_decay"], step=self._step, grad_norm_sq=norm,
+                           max_grad_norm=float(self.max_grad_norm or 0.0), params_bf16=self.mirror.bf16)
+            self.mirror.refresh(full=False)      # K-major copies for the backward GEMMs: one batched-transpose launch
         self.model.invalidate_packs()        # inference engine: re-pack at the next eval forward
         self._step_t += 1     # one tensor shared by every parameter's state entry
         return None

@@ -96,4 +96,5 @@ class DevicePreprocessor:
             crop_tl = None
         if self.noise > 0:
             seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
-        return ops.preprocess_u8(frames, self._th, self._tv, self.resized, out, self._tmp, crop_tl, self.noise, seed)
+        with torch.cuda.device(self.device):
+            return ops.preprocess_u8(frames, self._th, self._tv, self.resized, out, self._tmp, crop_tl, self.noise, seed)

@@ -211,6 +211,11 @@ class _TemporalFunction(torch.autograd.Function):
     def forward(ctx, feats, enc: TemporalEncoder, cls, train: bool, *params):
         if not feats.is_cuda:
             raise RuntimeError("the temporal encoder runs on the GPU through librvit only; there is no CPU fallback")
+        with torch.cuda.device(feats.device):   # librvit launches on the current device's stream
+            return _TemporalFunction._forward(ctx, feats, enc, cls, train)
+
+    @staticmethod
+    def _forward(ctx, feats, enc: TemporalEncoder, cls, train: bool):
         if feats.dim() != 3 or feats.shape[2] != enc.rnn.input_size:
             raise ValueError(f"expected features [B,T,{enc.rnn.input_size}], got {tuple(feats.shape)}")
         base = int(torch.randint(0, 2 ** 62, (1,)).item()) if train else 0
@@ -237,6 +242,11 @@ class _TemporalFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        with torch.cuda.device(dout.device):
+            return _TemporalFunction._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         enc, cls, saved = ctx.enc, ctx.cls, ctx.saved
         if saved[0]["gates"] is None:
             raise RuntimeError("backward through a forward that ran in eval mode / without grad")

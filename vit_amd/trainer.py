@@ -698,5 +698,6 @@ class HybridFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.eng
-        flat = eng.backward(dout.contiguous().float(), ctx.features_only, ctx.B)
+        with torch.cuda.device(dout.device):   # the autograd worker thread: launch on the tensors' device
+            flat = eng.backward(dout.contiguous().float(), ctx.features_only, ctx.B)
         return (None, None, None, *eng.grads_in_param_order(flat))
