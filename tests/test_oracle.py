@@ -138,3 +138,50 @@ def test_mxfp8_emulation_restatement_and_format():
     r = torch.randn(64, 256) * torch.exp(torch.randn(64, 1) * 4)
     err = (mx_fake_quant(r) - r).reshape(64, 8, 32).abs().amax(2)
     assert (err <= r.reshape(64, 8, 32).abs().amax(2) * 2.0 ** -3).all()
+
+
+def test_init_weights_semantics():
+    """`_init_weights` (train_vit.py:132-139) and the torch defaults the reference keeps everywhere else: trunc-normal
+    std 0.02 on pos_embed / cls_token / head Linear weights, zero head biases; MultiheadAttention in_proj
+    xavier-uniform with zero biases, out_proj bias zero; and - because nn.TransformerEncoder deep-copies ONE layer
+    (train_vit.py:103-116) - all encoder layers IDENTICAL at init.  Checked on the HIP model's parameter holder and
+    against the oracle (the same torch.nn constructors as the reference) built under the same seed statistics."""
+    import math
+    import torch
+    from oracle.ref_model import CNNViTHybridRef
+    from vit_amd.model import CNNViTHybrid
+    cfg = dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18")
+    torch.manual_seed(0)
+    m = CNNViTHybrid(**cfg)
+    torch.manual_seed(0)
+    ref = CNNViTHybridRef(**cfg)
+    sd, sr = m.state_dict(), ref.state_dict()
+    for k in ("pos_embed", "cls_token", "head.0.weight", "head.3.weight"):
+        for t in (sd[k], sr[k]):
+            assert abs(t.mean().item()) < 0.01 and t.abs().max().item() <= 2.0
+        # std 0.02 within sampling error (cls_token has only 256 values)
+        assert abs(sd[k].std().item() - 0.02) < (0.004 if sd[k].numel() < 1000 else 0.0015), k
+        assert abs(sr[k].std().item() - 0.02) < (0.004 if sr[k].numel() < 1000 else 0.0015), k
+    for k in ("head.0.bias", "head.3.bias"):
+        assert torch.count_nonzero(sd[k]) == 0 and torch.count_nonzero(sr[k]) == 0
+    E = cfg["embed_dim"]
+    for s in (sd, sr):
+        # identical layers at init
+        for i in range(1, cfg["num_layers"]):
+            for leaf in ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                         "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+                         "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias"):
+                assert torch.equal(s[f"transformer.layers.0.{leaf}"], s[f"transformer.layers.{i}.{leaf}"]), (i, leaf)
+        w = s["transformer.layers.0.self_attn.in_proj_weight"]
+        bound = math.sqrt(6.0 / (E + 3 * E))                       # xavier_uniform_ on [3E, E]
+        assert w.abs().max().item() <= bound + 1e-6 and abs(w.std().item() - bound / math.sqrt(3)) < 0.002
+        assert torch.count_nonzero(s["transformer.layers.0.self_attn.in_proj_bias"]) == 0
+        assert torch.count_nonzero(s["transformer.layers.0.self_attn.out_proj.bias"]) == 0
+        # nn.Linear default (kaiming_uniform a=sqrt(5)): U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias
+        for leaf, fan_in in (("linear1", E), ("linear2", 4 * E), ("self_attn.out_proj", E)):
+            w = s[f"transformer.layers.0.{leaf}.weight"]
+            assert w.abs().max().item() <= 1.0 / math.sqrt(fan_in) + 1e-6
+            assert abs(w.std().item() - 1.0 / math.sqrt(3 * fan_in)) < 0.1 / math.sqrt(3 * fan_in)
+        assert torch.equal(s["norm.weight"], torch.ones(E)) and torch.count_nonzero(s["norm.bias"]) == 0
+        pe = s["patch_embed.weight"]                               # nn.Conv2d default init, train_vit.py:93
+        assert pe.abs().max().item() <= 1.0 / math.sqrt(512) + 1e-6

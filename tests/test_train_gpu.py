@@ -157,3 +157,65 @@ def test_sgd_steps_reduce_the_loss(dev):
         losses.append(loss.item())
     print("losses", [round(v, 4) for v in losses])
     assert losses[-1] < losses[0]
+
+
+def test_frozen_backbone_skips_the_stem(dev):
+    """freeze_backbone / unfreeze_backbone of the reference (train_vit.py:310-318, 918-923): with every cnn_backbone
+    parameter at requires_grad=False the stem backward is skipped - its gradients stay None, every other gradient is
+    what the unfrozen step gives - and FusedAdamW steps only the unfrozen range: stem parameters (and their bf16
+    operand copies) keep their bits, no weight decay touches them; BatchNorm running statistics still move (train()
+    mode, as in the reference).  Unfreezing restores the full step; a partly frozen stem is refused."""
+    from vit_amd.loss import cross_entropy
+    from vit_amd.optim import FusedAdamW
+    from vit_amd.synth import micro_doppler_batch
+    name, cfg, B, _, _ = CASES[2]
+    m, _ = _pair(cfg, seed=6, dev=dev)
+    x = micro_doppler_batch(B, seed=2).to(dev)
+    y = torch.randint(0, 11, (B,), generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        cross_entropy(m(x), y, label_smoothing=0.05).backward()
+        return {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}
+
+    full = grads()
+    for p in m.cnn_backbone.parameters():
+        p.requires_grad = False
+    rm0 = m.cnn_backbone.bn1.running_mean.clone()
+    frozen = grads()
+    assert not torch.equal(rm0, m.cnn_backbone.bn1.running_mean)
+    for n, g in frozen.items():
+        if n.startswith("cnn_backbone."):
+            assert g is None, n
+        else:
+            rel = ((g - full[n]).norm() / full[n].norm().clamp_min(1e-20)).item()
+            assert rel < 1e-5, (n, rel)
+    # optimiser: only the unfrozen range moves
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=0.05, max_grad_norm=1.0)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    mirror0 = opt.mirror.bf16.clone()
+    grads()
+    opt.step()
+    start = m.train_engine.stem_start()
+    assert torch.equal(opt.mirror.bf16[start:], mirror0[start:]) and not torch.equal(opt.mirror.bf16[:start], mirror0[:start])
+    for n, p in m.named_parameters():
+        if n.startswith("cnn_backbone."):
+            assert torch.equal(p.detach(), before[n]), n
+        elif p.numel() > 16:
+            assert not torch.equal(p.detach(), before[n]), n
+    # grad-norm clipping saw the unfrozen gradients only
+    unfrozen_norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for n, p in m.named_parameters()
+                                   if not n.startswith("cnn_backbone.")))
+    assert torch.allclose(opt.grad_norm(), unfrozen_norm, rtol=1e-4)
+    # partly frozen: refused
+    next(iter(m.cnn_backbone.parameters())).requires_grad = True
+    with pytest.raises(RuntimeError):
+        grads()
+    # unfreeze: the stem trains again
+    for p in m.cnn_backbone.parameters():
+        p.requires_grad = True
+    again = grads()
+    assert all(g is not None for g in again.values())
+    opt.step()
+    assert not torch.equal(m.cnn_backbone.conv1.weight.detach(), before["cnn_backbone.conv1.weight"])

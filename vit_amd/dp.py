@@ -125,11 +125,14 @@ class BucketReducer:
         if upto - self.done >= self.bucket_elems:
             self._launch(flat, self.done, upto)
 
-    def finish(self, flat: torch.Tensor) -> None:
+    def finish(self, flat: torch.Tensor, limit: Optional[int] = None) -> None:
+        """Exchange what is left of [0, limit) (default: the whole buffer; a frozen stem leaves its tail out: every
+        rank must pass the same limit) and wait for every bucket of the step."""
         if self.world <= 1:
             return
-        if self.done < self.total:
-            self._launch(flat, self.done, self.total)
+        total = self.total if limit is None else min(int(limit), self.total)
+        if self.done < total:
+            self._launch(flat, self.done, total)
         for w in self._works:      # nccl: the compute stream waits for the group's stream; gloo: the host waits
             w.wait()
         self._works = []

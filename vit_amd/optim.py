@@ -65,11 +65,18 @@ class FusedAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("FusedAdamW: closures are not supported")
-        if not all(p.requires_grad for p in self.param_groups[0]["params"]):
-            # torch optimisers skip parameters without a gradient (freeze_backbone, train_vit.py:310-318); the flat
-            # kernels update every element, weight decay included, so refuse instead of silently unfreezing
-            raise RuntimeError("FusedAdamW: frozen parameters (requires_grad=False) are not supported; "
-                               "use a torch optimiser while part of the model is frozen")
+        # torch optimisers skip parameters without a gradient (freeze_backbone, train_vit.py:310-318).  The flat
+        # kernels update a contiguous range; the stem's parameters are the TAIL of the flat layout, so a frozen
+        # cnn_backbone simply shortens the range (no weight decay, no moment update on it: as torch).  Any other
+        # frozen subset is refused rather than silently stepped.
+        n_active = self._eng.layout.total
+        frozen = {id(p) for p in self.param_groups[0]["params"] if not p.requires_grad}
+        if frozen:
+            cb = self.model.cnn_backbone
+            if cb is None or frozen != {id(p) for p in cb.parameters()}:
+                raise RuntimeError("FusedAdamW: the only frozen set supported is the whole cnn_backbone "
+                                   "(freeze_backbone, train_vit.py:310-318); use a torch optimiser for other subsets")
+            n_active = self._eng.stem_start()
         flat_g = getattr(self._eng, "last_flat", None)
         first = self._probe[0][0]
         if flat_g is None or first.grad is None:
@@ -87,13 +94,15 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step += 1
         norm = None
         with torch.cuda.device(self.flat_params.device):
+            act = slice(0, n_active)
             if self.max_grad_norm is not None:
                 self._norm_sq.zero_()
-                norm = ops.sumsq(flat_g, self._norm_sq)
+                norm = ops.sumsq(flat_g[act], self._norm_sq)
             b1, b2 = grp["betas"]
-            ops.adamw_step(self.flat_params, flat_g, self.exp_avg, self.exp_avg_sq, lr=grp["lr"], beta1=b1, beta2=b2,
-                           eps=grp["eps"], weight_decay=grp["weight_decay"], step=self._step, grad_norm_sq=norm,
-                           max_grad_norm=float(self.max_grad_norm or 0.0), params_bf16=self.mirror.bf16)
+            ops.adamw_step(self.flat_params[act], flat_g[act], self.exp_avg[act], self.exp_avg_sq[act], lr=grp["lr"],
+                           beta1=b1, beta2=b2, eps=grp["eps"], weight_decay=grp["weight_decay"], step=self._step,
+                           grad_norm_sq=norm, max_grad_norm=float(self.max_grad_norm or 0.0),
+                           params_bf16=self.mirror.bf16[act])
             self.mirror.refresh(full=False)      # K-major copies for the backward GEMMs: one batched-transpose launch
         self.model.invalidate_packs()        # inference engine: re-pack at the next eval forward
         self._step_t += 1     # one tensor shared by every parameter's state entry

@@ -637,22 +637,29 @@ class TrainEngine:
             ops.dropout_apply(dxs_bf, dxs_bf, dp, sd(SITE_POS))
         ops.batch_sum(dxs.view(B, S * E), g("pos_embed"))
         g("cls_token").copy_(g("pos_embed")[:E])
+        limit = None
         if m.cnn_backbone is not None:
             feat = b["feat"]
             ops.wgrad(dxs_bf, feat.view(B * NP, -1), g2("patch_embed.weight", E), rows=B * NP, y_row_group=NP,
                       y_row_extra=1)
             ops.colsum(dxs_bf, g("patch_embed.bias"), rows=B * NP, row_group=NP, row_extra=1)
-            dfeat = self._scratch(b, ("dfeat",), feat)
-            ops.gemm(dxs_bf, P["pe_wt"], dfeat.view(B * NP, -1), a_rows=B * NP, a_row_group=NP, a_row_extra=1)
-            self._maybe_reduce(flat, "patch_embed.bias")
-            self._stem_backward(P, b, B, flat, dfeat)
+            if self.stem_frozen():
+                # freeze_backbone (train_vit.py:310-313): no parameter below the patch embedding wants a gradient and
+                # the image needs none, so the whole stem backward (2/3 of the step's FLOPs) is skipped; the stem's
+                # segment of the flat buffer (its tail) stays zero and is neither exchanged nor stepped
+                limit = self.stem_start()
+            else:
+                dfeat = self._scratch(b, ("dfeat",), feat)
+                ops.gemm(dxs_bf, P["pe_wt"], dfeat.view(B * NP, -1), a_rows=B * NP, a_row_group=NP, a_row_extra=1)
+                self._maybe_reduce(flat, "patch_embed.bias")
+                self._stem_backward(P, b, B, flat, dfeat)
         else:
             dpatch = dxs_bf.view(B, S, E)[:, 1:].contiguous().view(B, 14, 14, E)
             dw = torch.zeros(E, 16 * 64, dtype=F32, device=dev)
             ops.conv2d_wgrad(dpatch, b["img"], dw, kh=16, kw=1, stride=16, pad=0, seg_len=64)
             g("patch_embed.weight").view(E, 16, 16, 3).copy_(dw.view(E, 16, 16, 4)[..., :3])
             ops.colsum(dpatch.view(B * NP, E), g("patch_embed.bias"))
-        self._finish_reduce(flat)
+        self._finish_reduce(flat, limit)
         self.last_flat = flat  # vit_amd.optim.FusedAdamW reads the gradients straight from here
         return flat
 
@@ -664,9 +671,23 @@ class TrainEngine:
         off, n, _ = self.layout.offsets[last_done_name]
         self.reducer.ready(flat, off + (n + 63) // 64 * 64)
 
-    def _finish_reduce(self, flat) -> None:
+    def _finish_reduce(self, flat, limit=None) -> None:
         if self.reducer is not None:
-            self.reducer.finish(flat)
+            self.reducer.finish(flat, limit)
+
+    # ---- frozen backbone (train_vit.py:310-318) ------------------------------------------------------
+    def stem_start(self) -> int:
+        """Offset of the first cnn_backbone.* segment: the stem's parameters are the TAIL of the flat layout."""
+        return min(off for n, (off, _, _) in self.layout.offsets.items() if n.startswith("cnn_backbone."))
+
+    def stem_frozen(self) -> bool:
+        cb = self.m.cnn_backbone
+        if cb is None:
+            return False
+        flags = [p.requires_grad for p in cb.parameters()]
+        if any(flags) and not all(flags):
+            raise RuntimeError("cnn_backbone is partly frozen: freeze or unfreeze all of it (train_vit.py:310-318)")
+        return not flags[0]
 
     def grads_in_param_order(self, flat) -> List[torch.Tensor]:
         out = []
@@ -700,4 +721,5 @@ class HybridFunction(torch.autograd.Function):
         eng = ctx.eng
         with torch.cuda.device(dout.device):   # the autograd worker thread: launch on the tensors' device
             flat = eng.backward(dout.contiguous().float(), ctx.features_only, ctx.B)
-        return (None, None, None, *eng.grads_in_param_order(flat))
+        need = ctx.needs_input_grad[3:]
+        return (None, None, None, *[g if n else None for g, n in zip(eng.grads_in_param_order(flat), need)])
