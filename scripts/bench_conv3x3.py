@@ -25,8 +25,8 @@ def bench(fn, iters=30):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     dev = torch.device("cuda:0")
-    for name, c, hw, tiles in (("layer1", 64, 56, (11, 14)), ("layer2", 128, 28, (11, 12, 13)), ("layer3", 256, 14, (11, 12, 13)),
-                               ("layer4", 512, 7, (11, 12, 13))):
+    for name, c, hw, tiles in (("layer1", 64, 56, (11, 14)), ("layer2", 128, 28, (11, 16, 17)), ("layer3", 256, 14, (11, 15, 16, 17, 18)),
+                               ("layer4", 512, 7, (11, 15, 16, 17, 18))):
         x = torch.randn(B, hw, hw, c, device=dev).bfloat16()
         w = (torch.randn(c, 9 * c, device=dev) / (3 * c ** 0.5)).bfloat16()
         res = torch.randn(B, hw, hw, c, device=dev).bfloat16()
@@ -34,9 +34,13 @@ def main():
         out = torch.empty_like(x)
         fl = 2.0 * B * hw * hw * c * c * 9
         for tile in tiles:
-            for with_res in (False, True):
+            for with_res in (False,):
                 kw = dict(scale=scale, bias=bias, act="relu", residual=res if with_res else None)
-                us = bench(lambda: ops.conv2d(x, w, out, kh=3, kw=3, stride=1, pad=1, tile=tile, **kw))
+                try:
+                    us = bench(lambda: ops.conv2d(x, w, out, kh=3, kw=3, stride=1, pad=1, tile=tile, **kw))
+                except Exception as e:  # noqa: BLE001
+                    print(f"{name} tile={tile}: {str(e)[-90:]}")
+                    continue
                 nbytes = x.numel() * 2 * (3 if with_res else 2)
                 print(f"{name} B={B} tile={tile} residual={int(with_res)}: {us:7.1f} us  {fl / us / 1e6:6.0f} TF/s  "
                       f"{nbytes / us / 1e6:5.2f} TB/s algorithmic", flush=True)

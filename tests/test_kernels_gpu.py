@@ -294,7 +294,7 @@ def test_errors_are_loud(dev):
 @pytest.mark.parametrize("cin,cout,hw,B", [(64, 64, 56, 2), (128, 128, 28, 3), (256, 256, 14, 5), (512, 512, 7, 11),
                                             (64, 128, 14, 1), (128, 64, 7, 40), (128, 256, 28, 2), (384, 128, 14, 3)])
 @pytest.mark.parametrize("plain", [False, True])
-@pytest.mark.parametrize("variant", [11, 12, 13, 15])
+@pytest.mark.parametrize("variant", [11, 12, 13, 15, 16, 17, 18])
 def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant):
     """The LDS-resident 3x3/1 kernel (tile 10, csrc/conv3x3.hip) against torch and against the gather
     kernel (tile 1): tiles that straddle image rows and image boundaries (M = B*hw*hw is not a
@@ -303,8 +303,10 @@ def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant)
     from vit_amd import ops
     if variant == 12 and (cout % 128 or cin % 128):
         pytest.skip("the 128-channel variant needs Cout (forward) and Cin (dgrad) multiples of 128")
-    if variant == 15 and (cout % 256 or cin % 256):
-        pytest.skip("the 256-channel sixteen-wave variant (layer4) needs Cout and Cin multiples of 256")
+    if variant in (15, 18) and (cout % 256 or cin % 256):
+        pytest.skip("the 256-channel sixteen-wave variants need Cout and Cin multiples of 256")
+    if variant in (16, 17) and hw == 56:
+        pytest.skip("a 56-wide patch and a 3- / 4-stage weight ring do not fit the LDS")
     g = torch.Generator().manual_seed(cin + cout + hw + B)
     x = _bf(torch.randn(B, hw, hw, cin, generator=g))
     w = _bf(torch.randn(cout, 3, 3, cin, generator=g) / math.sqrt(9 * cin))
@@ -323,6 +325,9 @@ def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant)
     ops.conv2d(x.to(dev), w.reshape(cout, -1).to(dev), out1, kh=3, kw=3, stride=1, pad=1, tile=1, **kw)
     # same products, different fp32 summation order: at most an ulp of bf16 apart
     assert (out.float() - out1.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, out1.float().abs().max().item())
+    if variant >= 15:   # every direct variant contracts K in the order of the 64-channel kernel: identical bits
+        ops.conv2d(x.to(dev), w.reshape(cout, -1).to(dev), out1, kh=3, kw=3, stride=1, pad=1, tile=11, **kw)
+        assert torch.equal(out, out1)
     # input gradient = the same kernel on dy with flipped taps and [Cin, kh, kw, Cout] weights
     dy = _bf(torch.randn(B, hw, hw, cout, generator=g))
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)

@@ -24,12 +24,35 @@
 // Structure: 8 waves, v_mfma_f32_16x16x32_bf16 with the weights on the A side, two variants (below);
 // epilogue identical to gemm.hip's (accumulators restaged through LDS, whole 128-byte row
 // segments to global; folded-BN scale/bias, residual, ReLU).
+#include <stdlib.h>
+
 #include "common.h"
 #include "rvit_internal.h"
 
 namespace {
 
 __device__ uint4 g_zero_page_c3[4];
+// Diagnosis builds only (never the shipped library): -DRVIT_C3_ABLATE compiles run-time skip masks into the kernel
+// (RVIT_C3_ABLATE env: bit 0 no MFMA, 1 no fragment reads, 2 no weight DMA, 3 no patch DMA, 4 no epilogue, 5 no
+// per-tap barrier; results are wrong, timing attribution only - and the branches themselves cost ~25 %, so compare
+// masks with mask 0 of the SAME build); -DRVIT_C3_STAMPS records s_memtime per workgroup phase (scripts/c3_stamps.py).
+#ifdef RVIT_C3_ABLATE
+#define C3_ABL(bit) ((ablate & (bit)) != 0)
+#else
+#define C3_ABL(bit) false
+#endif
+#ifdef RVIT_C3_STAMPS
+__device__ unsigned long long g_c3_stamps[8192 * 8];
+#define C3_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_c3_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define C3_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define C3_ACC(dst, a, b) dst += (b) - (a)
+#define C3_PUT(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_c3_stamps[blockIdx.x * 8 + (k)] = (v); } while (0)
+#else
+#define C3_STAMP(k) do {} while (0)
+#define C3_T(var) do {} while (0)
+#define C3_ACC(dst, a, b) do {} while (0)
+#define C3_PUT(k, v) do {} while (0)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
@@ -125,8 +148,12 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
 //           workgroup per CU (<= 152 KB) keeps the MFMA pipe busy by itself.
 // tile_len: output pixels per workgroup: 256 consecutive pixels, or (wide maps) a whole number of
 // image rows <= 256 so that the patch is (rows + 2) x (W + 2).
-template <int BN, bool DB, int C3_WAVES>
-__global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2) void conv3x3_direct_kernel(const GemmArgs p, int patch_bytes, int tile_len) {
+// RING: stages of the weight-tile ring.  The tile of tap s + RING - 1 is issued at tap s, so RING - 1 tiles (8-32 KB)
+// are in flight per workgroup: with RING = 2 a tile has exactly one tap (~500 MFMA clocks per SIMD) to cross
+// L2 -> LDS, which is about the latency of an LDS-DMA under load, and every tap stalled on it.
+template <int BN, bool DB, int C3_WAVES, int RING = 2>
+__global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2) void conv3x3_direct_kernel(const GemmArgs p, int patch_bytes, int tile_len, int ablate) {
+  static_assert(RING >= 2 && (RING == 2 || !DB), "deep weight rings are built for the single-patch-buffer variants");
   constexpr int WAVES_N = BN / 64, WAVES_M = C3_WAVES / WAVES_N;
   constexpr int WM = C3_BM / WAVES_M, MR = WM / 16;
   constexpr int C3_PIT = C3_PMAX / 8 / C3_WAVES;  // patch DMA passes per wave
@@ -134,6 +161,7 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
   constexpr int B_LOADS = BN / B_ROWS;        // weight-tile DMA instructions per thread per tap
   constexpr int B_STAGE = BN * 128;           // bytes of one weight tile (BN rows x 64 k)
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  C3_STAMP(0);
   char* const bring = smem + (DB ? 2 : 1) * patch_bytes;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -216,8 +244,9 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
 
 #define ISSUE_B(step_, c0_, tapw_)                                                      \
   do {                                                                                  \
-    char* d_ = b_dst + ((step_) & 1) * B_STAGE;                                         \
+    char* d_ = b_dst + ((step_) % RING) * B_STAGE;                                      \
     const bf16* s_ = b_base + (long)(tapw_) * Cin + (c0_);                              \
+    if (!C3_ABL(4))                                                                  \
     _Pragma("unroll") for (int l_ = 0; l_ < B_LOADS; ++l_)                              \
       glds16(s_ + (long)l_ * B_ROWS * p.ldb, d_ + l_ * B_ROWS * 128);                   \
   } while (0)
@@ -225,17 +254,33 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
   do {                                                                                  \
     const int pass_ = wave + (it_) * C3_WAVES;                                          \
     const bf16* src_ = pix[it_] >= 0 ? p.A + (long)pix[it_] * Cin + (c0_) + pchunk : zero_src; \
-    glds16(src_, smem + (buf_) * patch_bytes + pass_ * 1024);                           \
+    if (!C3_ABL(8)) glds16(src_, smem + (buf_) * patch_bytes + pass_ * 1024);        \
   } while (0)
 
 #define C3_TAP_BODY(tap) \
-      if (tap != 0 && pend) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); \
-      else wait_vm0(); \
-      __builtin_amdgcn_s_barrier(); \
-      if (tap < 8) { \
-        ISSUE_B(step + 1, c0, flip ? 7 - tap : tap + 1); \
-      } else if (has_next) { \
-        ISSUE_B(step + 1, c0 + 64, flip ? 8 : 0); \
+      C3_T(t0_); \
+      if constexpr (RING == 2) { \
+        if (tap != 0 && pend) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); \
+        else wait_vm0(); \
+      } else { \
+        /* tap 0: the slice's patch (issued after the tiles in flight) must have landed too */ \
+        if (tap == 0) wait_vm0(); \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 2) * B_LOADS) : "memory"); \
+      } \
+      C3_T(t1_); \
+      if (!C3_ABL(32)) __builtin_amdgcn_s_barrier(); \
+      C3_T(t2_); \
+      C3_ACC(tw_vm, t0_, t1_); C3_ACC(tw_bar, t1_, t2_); \
+      if constexpr (RING == 2) { \
+        if (tap < 8) { \
+          ISSUE_B(step + 1, c0, flip ? 7 - tap : tap + 1); \
+        } else if (has_next) { \
+          ISSUE_B(step + 1, c0 + 64, flip ? 8 : 0); \
+        } \
+      } else { \
+        /* tile of tap step + RING - 1 (past the end: tap 0 again, never read; keeps the vmcnt count uniform) */ \
+        ISSUE_B(step + RING - 1, iss_c0, flip ? 8 - iss_tap : iss_tap); \
+        if (++iss_tap == 9) { iss_tap = 0; iss_c0 += 64; if (iss_c0 >= Cin) iss_c0 = 0; } \
       } \
       pend = false; \
       if constexpr (DB) { \
@@ -246,23 +291,28 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
       } \
       if (wave_live) { \
         const int roff = (tap / 3) * PW + (tap % 3); \
-        const char* sB = bring + (step & 1) * B_STAGE + wn * 8192; \
+        const char* sB = bring + (step % RING) * B_STAGE + wn * 8192; \
 _Pragma("unroll") \
         for (int ks = 0; ks < 2; ++ks) { \
           bf16x8 af[MR], bfr[4]; \
 _Pragma("unroll") \
           for (int i = 0; i < MR; ++i) { \
             const int row = pb[i] + roff; \
-            af[i] = *reinterpret_cast<const bf16x8*>(patch + row * 128 + (((ks * 4 + fq) ^ (row & 6)) << 4)); \
+            if (!C3_ABL(2)) af[i] = *reinterpret_cast<const bf16x8*>(patch + row * 128 + (((ks * 4 + fq) ^ (row & 6)) << 4)); \
+            else asm volatile("" : "=v"(af[i])); \
           } \
 _Pragma("unroll") \
-          for (int j = 0; j < 4; ++j) \
-            bfr[j] = *reinterpret_cast<const bf16x8*>(sB + (j * 16 + fr) * 128 + (((ks * 4 + fq) ^ sw_b) << 4)); \
+          for (int j = 0; j < 4; ++j) { \
+            if (!C3_ABL(2)) bfr[j] = *reinterpret_cast<const bf16x8*>(sB + (j * 16 + fr) * 128 + (((ks * 4 + fq) ^ sw_b) << 4)); \
+            else asm volatile("" : "=v"(bfr[j])); \
+          } \
+          if (!C3_ABL(1)) \
 _Pragma("unroll") \
           for (int i = 0; i < MR; ++i) \
 _Pragma("unroll") \
             for (int j = 0; j < 4; ++j) \
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0); \
+          else { _Pragma("unroll") for (int i = 0; i < MR; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(bfr[j]), "v"(af[i])); } \
         } \
       } \
       ++step;
@@ -273,7 +323,19 @@ _Pragma("unroll") \
   for (int it = 0; it < C3_PIT; ++it)
     if (wave + it * C3_WAVES < npass) ISSUE_PATCH_PASS(it, 0, 0);
   ISSUE_B(0, 0, flip ? 8 : 0);
+  int iss_tap = 1, iss_c0 = 0;   // RING > 2: (tap, slice) of the next weight tile to issue
+  if constexpr (RING > 2) {
+#pragma unroll
+    for (int s_ = 1; s_ < RING - 1; ++s_) {
+      ISSUE_B(s_, iss_c0, flip ? 8 - iss_tap : iss_tap);
+      ++iss_tap;
+    }
+  }
 
+  C3_STAMP(1);
+#ifdef RVIT_C3_STAMPS
+  unsigned long long tw_vm = 0, tw_bar = 0;
+#endif
   int step = 0;
   bool pend = false;  // a patch pass of the NEXT slice was issued after the latest weight tile
   for (int c = 0; c < nchunks; ++c) {
@@ -305,8 +367,17 @@ _Pragma("unroll") \
 #undef C3_TAP_BODY
 #undef ISSUE_B
 #undef ISSUE_PATCH_PASS
+  if constexpr (RING > 2) wait_vm0();   // the tiles issued past the end: the epilogue staging aliases the ring
 
+  C3_STAMP(2);
+  C3_PUT(4, tw_vm);
+  C3_PUT(5, tw_bar);
+  if (C3_ABL(16)) {
+    if (acc[0][0][0] == 123.456f) *reinterpret_cast<float*>(p.C) = 1.f;   // keep the loop alive
+    return;
+  }
   c3_epilogue<MR, WM, (C3_WAVES == 16 ? 16 : WM)>(p, smem, acc, wave, lane, wm, wn, m0, m_last, n0);
+  C3_STAMP(3);
 }
 
 }  // namespace
@@ -340,17 +411,24 @@ bool rvit_conv3x3_direct_ok(const GemmArgs& a) {
   return (long)a.M / ((long)a.H * a.W) * (a.H + 2) < 0x7fffffffL / (a.W + 2);
 }
 
-template <int BN, bool DB, int C3_WAVES>
+// RVIT_C3_ABLATE (diagnosis only; results are WRONG when set): bit 0 no MFMA, 1 no fragment reads, 2 no weight DMA,
+// 3 no patch DMA, 4 no epilogue, 5 no per-tap barrier.  Timing attribution for profiles/ notes.
+static int c3_ablate() {
+  static const int v = [] { const char* e = getenv("RVIT_C3_ABLATE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+template <int BN, bool DB, int C3_WAVES, int RING = 2>
 static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream_t st) {
-  int lds = (DB ? 2 : 1) * patch_bytes + 2 * BN * 128;
+  int lds = (DB ? 2 : 1) * patch_bytes + RING * BN * 128;
   const int ep = (C3_WAVES == 16 ? 16 * 16 : C3_BM * (BN / 64)) * (64 * 4 + 16);   // wave-private epilogue staging, all waves
   if (lds < ep) lds = ep;
   static RvitLdsLimit lim;
-  if (const int rc = lim.ensure({(const void*)conv3x3_direct_kernel<BN, DB, C3_WAVES>}, lds, "conv3x3")) return rc;
+  if (const int rc = lim.ensure({(const void*)conv3x3_direct_kernel<BN, DB, C3_WAVES, RING>}, lds, "conv3x3")) return rc;
   const long tiles = ((a.M + tile_len - 1) / tile_len) * (long)(a.N / BN);
   if (tiles <= 0) return RVIT_OK;
   RVIT_CHECK_ARG(tiles < 0x7fffffffL, "conv3x3: too many tiles");
-  hipLaunchKernelGGL((conv3x3_direct_kernel<BN, DB, C3_WAVES>), dim3((unsigned)tiles), dim3(64 * C3_WAVES), lds, st, a, patch_bytes, tile_len);
+  hipLaunchKernelGGL((conv3x3_direct_kernel<BN, DB, C3_WAVES, RING>), dim3((unsigned)tiles), dim3(64 * C3_WAVES), lds, st, a, patch_bytes, tile_len, c3_ablate());
   RVIT_CHECK_LAUNCH("conv3x3_direct");
   return RVIT_OK;
 }
@@ -382,6 +460,10 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
     wide = true;
   }
   if (variant == 3) return c3_launch<64, false, 4>(a, patch_bytes, tile_len, st);
+  // experiments (tiles 16-19): deeper weight rings
+  if (variant == 6) { RVIT_CHECK_ARG(patch_bytes + 3 * 64 * 128 <= 160 * 1024, "conv3x3: ring 3 does not fit"); return c3_launch<64, false, 8, 3>(a, patch_bytes, tile_len, st); }
+  if (variant == 7) { RVIT_CHECK_ARG(patch_bytes + 4 * 64 * 128 <= 160 * 1024, "conv3x3: ring 4 does not fit"); return c3_launch<64, false, 8, 4>(a, patch_bytes, tile_len, st); }
+  if (variant == 8) { RVIT_CHECK_ARG((a.N & 255) == 0 && patch_bytes + 3 * 256 * 128 <= 160 * 1024, "conv3x3: c256 ring 3 does not fit"); return c3_launch<256, false, 16, 3>(a, patch_bytes, tile_len, st); }
   // 256 output channels per workgroup, sixteen waves of 64 x 64, one workgroup per CU: the patch is staged once per
   // 256 instead of 64 output channels and the fragment reads per MFMA drop from 0.75 to 0.5.  Same K order (bit-identical).
   // B=512: layer4 (512 -> 512, 7x7) 151 -> 135 us, layer3 (256 -> 256) 148 -> 144 us; automatic for >= 512 input
@@ -391,3 +473,9 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
   if (variant == 5 || (variant == 0 && c256_ok && a.Cpix >= 512)) return c3_launch<256, false, 16>(a, patch_bytes, tile_len, st);
   return wide ? c3_launch<128, true, 8>(a, patch_bytes, tile_len, st) : c3_launch<64, false, 8>(a, patch_bytes, tile_len, st);
 }
+
+#ifdef RVIT_C3_STAMPS
+extern "C" int rvit_debug_c3_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_c3_stamps), (size_t)n * 8);
+}
+#endif

@@ -324,7 +324,7 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   // at every batch size: the kernel choice must not depend on M or a sample's logits would depend on
   // the batch it travels in (fp32 summation order differs between the two kernels);
   // tile 10 forces it (11 / 12 / 13 / 14 / 15: its 64- / 128-channel / 4-wave / weights-resident / 256-channel variant), any other non-zero tile forces the gather kernel (tests compare the two)
-  if (a.tile == 0 || (a.tile >= 10 && a.tile <= 15)) {
+  if (a.tile == 0 || (a.tile >= 10 && a.tile <= 19)) {
     const bool ok = rvit_conv3x3_direct_ok(a);
     if (ok) return rvit_conv3x3_direct(a, a.tile >= 10 ? a.tile - 10 : 0, stream);
     if (a.tile >= 10) {

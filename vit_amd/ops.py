@@ -254,7 +254,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
     # the 3x3 / stride 1 / pad 1 convs run the LDS-resident-patch kernel (csrc/conv3x3.hip), everything else
     # the implicit-GEMM gather kernel (csrc/gemm.hip): profile them under separate names
     direct = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and seg_len is None and Cpix % 64 == 0
-              and Cout % 64 == 0 and (tile == 0 or 10 <= tile <= 15))
+              and Cout % 64 == 0 and (tile == 0 or 10 <= tile <= 19))
     # ... and among those the 64 -> 64 channel convs on 56-wide maps (layer1) the weights-resident kernel
     # (csrc/conv3x3_c64.hip; same conditions as rvit_conv3x3_c64_ok)
     c64 = (direct and tile in (0, 14) and Cpix == 64 and Cout == 64 and W == 56 and H % 4 == 0
