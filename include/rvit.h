@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 10
+#define RVIT_ABI_VERSION 11
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -169,6 +169,13 @@ int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int 
  *   scale/bias: f32 [64];  pooled: bf16 [B,56,56,64];  relu != 0 applies the ReLU. */
 int rvit_stem_conv1_pool_fwd(const void* img, const void* w, const float* scale, const float* bias, void* pooled, int B,
                              int relu, void* stream);
+
+/* The same stem entry straight from the model's input tensor: x_nchw f32 [B,3,224,224] contiguous, 16-byte aligned
+ * (CNNViTHybrid.forward's argument, train_vit.py:141-146).  The bf16 NHWC4 patch is built in LDS by the kernel itself,
+ * so the separate rvit_input_pack_nhwc4 pass and its 427 KB/sample buffer are not needed; results are bit-identical
+ * to rvit_input_pack_nhwc4 + rvit_stem_conv1_pool_fwd.  What eval-mode inference runs. */
+int rvit_stem_conv1_pool_f32_fwd(const float* x_nchw, const void* w, const float* scale, const float* bias, void* pooled,
+                                 int B, int relu, void* stream);
 
 /* fp32 NCHW image batch -> zero-haloed bf16 NHWC4 (channel 3 = 0).  Input contract of
  * CNNViTHybrid.forward (train_vit.py:141-146: x is [B,3,224,224] float).  Writes only the

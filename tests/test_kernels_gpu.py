@@ -434,3 +434,7 @@ def test_stem_conv1_pool_fused(dev, B):
     diff = (pooled.float() - p2.float()).abs()
     assert (diff > 0).float().mean().item() < 1e-3
     assert diff.max().item() <= 2.0 ** -7 * max(1.0, p2.float().abs().max().item())
+    # the form inference runs: the patch built in LDS from the fp32 NCHW input itself (no packed copy) - same bits
+    p3 = torch.full_like(pooled, float("nan"))
+    ops.stem_conv1_pool_f32(x.to(dev), w232.to(dev), scale.to(dev), bias.to(dev), p3)
+    assert torch.equal(p3, pooled)

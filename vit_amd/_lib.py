@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "rvit_linear_wgrad_bias_bf16": ([P, L, P, L, P, L, P, L, I, I, I, I, P], c_int),
     "rvit_conv2d_wgrad_bf16": ([P, P, P] + [I] * 12 + [I, P], c_int),
     "rvit_stem_conv1_pool_fwd": ([P, P, P, P, P, I, I, P], c_int),
+    "rvit_stem_conv1_pool_f32_fwd": ([P, P, P, P, P, I, I, P], c_int),
     "rvit_input_pack_nhwc4": ([P, P] + [I] * 8 + [P], c_int),
     "rvit_maxpool3x3s2_nhwc": ([P, P, P] + [I] * 4 + [P], c_int),
     "rvit_embed_cls": ([P, P, P, I, I, I, F, U64, P], c_int),

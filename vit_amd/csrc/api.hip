@@ -248,7 +248,12 @@ int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int 
 
 int rvit_stem_conv1_pool_fwd(const void* img, const void* w, const float* scale, const float* bias, void* pooled, int B,
                              int relu, void* stream) {
-  return rvit_stem_conv1_pool_impl(img, w, scale, bias, pooled, B, relu, (hipStream_t)stream);
+  return rvit_stem_conv1_pool_impl(img, w, scale, bias, pooled, B, relu, 0, (hipStream_t)stream);
+}
+
+int rvit_stem_conv1_pool_f32_fwd(const float* x_nchw, const void* w, const float* scale, const float* bias, void* pooled,
+                                 int B, int relu, void* stream) {
+  return rvit_stem_conv1_pool_impl(x_nchw, w, scale, bias, pooled, B, relu, 1, (hipStream_t)stream);
 }
 
 int rvit_input_pack_nhwc4(const float* x_nchw, void* out, int B, int C, int H, int W, int Hp, int Wp, int pad_top,

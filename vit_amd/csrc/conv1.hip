@@ -26,6 +26,12 @@
 namespace {
 
 __device__ uint4 g_zero_page_c1[4];
+#ifdef RVIT_C1_STAMPS   // diagnosis build only: s_memtime per workgroup phase (scripts/c1_stamps.py)
+__device__ unsigned long long g_c1_stamps[16384 * 8];
+#define C1_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_c1_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C1_STAMP(k) do {} while (0)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
@@ -47,11 +53,20 @@ constexpr int CO_BYTES = NCR * WC * CO_PITCH;  // 80640
 constexpr int NBLK = NCR * (WC / 16);      // 35 blocks of 16 pixels
 constexpr int BLK_PER_WAVE = (NBLK + 7) / 8;   // 5
 
-__global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const bf16* __restrict__ img, const bf16* __restrict__ w,
+// F32IN: the patch is built in LDS straight from the caller's fp32 NCHW image [B,3,224,224] (the model's input
+// contract, train_vit.py:141-146) instead of being DMA'd from the packed bf16 NHWC4 copy: the separate pack pass
+// (rvit_input_pack_nhwc4: 308 MB read + 218 MB written + 92 us per 512 frames) disappears.  A thread converts quads
+// of four pixels (three 16-byte loads, one per channel plane) to four (c0, c1, c2, 0) bf16 pixels; halo rows and
+// columns come from zero-filling the patch first.  The bf16 values equal the pack kernel's, so both forms give
+// identical results.
+template <bool F32IN>
+__global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const void* __restrict__ img_any, const bf16* __restrict__ w,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ bias, bf16* __restrict__ pooled,
                                                             int relu) {
+  const bf16* __restrict__ img = static_cast<const bf16*>(img_any);
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  C1_STAMP(0);
   char* const sW = smem;
   char* const sP = smem + W_BYTES;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -65,15 +80,56 @@ __global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const bf16* __restri
 
   // ---- stage weights (29 x 1 KB) and the image patch (<= 28 x 1 KB), both contiguous copies ---------
   for (int i = wave; i < W_BYTES / 1024; i += 8) glds16(reinterpret_cast<const char*>(w) + i * 1024 + lane * 16, sW + i * 1024);
-  {
+  if constexpr (!F32IN) {
     const char* src = reinterpret_cast<const char*>(img) + ((long)b * HP + prow0) * ROW_B;
     for (int i = wave; i < PATCH_BYTES / 1024; i += 8) {
       const int off = i * 1024 + lane * 16;
       glds16(off < pbytes ? (const void*)(src + off) : (const void*)zero_src, sP + i * 1024);
     }
+  } else {
+    (void)pbytes; (void)zero_src;
+    const float* __restrict__ x = static_cast<const float*>(img_any) + (long)b * 3 * 224 * 224;
+    const int nrows = prow1 - prow0 + 1;                 // <= 15 padded rows; padded row pr = image row pr - 3
+    // issue the loads first (2 units of 4 pixels x 3 planes per thread), zero the patch while they fly
+    constexpr int UNITS = 15 * 56, UPT = (UNITS + 511) / 512;   // 2
+    float4 v[UPT][3];
+    int dst[UPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int id = t + u * 512;
+      const int r = id / 56, j = id - r * 56;
+      const int ir = prow0 + r - 3;
+      dst[u] = -1;
+      if (r < nrows && (unsigned)ir < 224u) {
+        const float* src = x + (long)ir * 224 + 4 * j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[u][c] = *reinterpret_cast<const float4*>(src + (long)c * 224 * 224);
+        dst[u] = r * ROW_B + (4 * j + 3) * 8;             // padded column 4j + 3, 8 bytes per pixel
+      }
+    }
+    for (int i = t; i < PATCH_BYTES / 16; i += 512) *reinterpret_cast<uint4*>(sP + i * 16) = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      if (dst[u] < 0) continue;
+      const float p0[4] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w};
+      const float p1[4] = {v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+      const float p2[4] = {v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
+      uint2 px[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        px[e].x = pack_bf16x2(p0[e], p1[e]);
+        px[e].y = pack_bf16x2(p2[e], 0.f);
+      }
+      char* d = sP + dst[u];                               // 8-byte aligned (offset 24 mod 32)
+      *reinterpret_cast<uint2*>(d) = px[0];
+      *reinterpret_cast<uint4*>(d + 8) = uint4{px[1].x, px[1].y, px[2].x, px[2].y};
+      *reinterpret_cast<uint2*>(d + 24) = px[3];
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  C1_STAMP(1);
 
   // ---- MFMA: each wave owns up to 5 blocks of 16 pixels x 64 channels ----------------------------------
   const int fr = lane & 15, fq = lane >> 4;
@@ -103,7 +159,9 @@ __global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const bf16* __restri
       for (int j = 0; j < 4; ++j) acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[q][j], 0, 0, 0);
     }
   }
+  C1_STAMP(2);
   __syncthreads();  // patch and weights are dead: the conv-out map aliases them
+  C1_STAMP(3);
 
   // ---- scale / bias / ReLU -> bf16 conv-out map in LDS ([NCR][112] pixels, 144 B pitch) -----------------
   // lane holds channels 16j + 4fq + (0..3) of pixel fr of each of its blocks
@@ -124,10 +182,7 @@ __global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const bf16* __restri
     for (int j = 0; j < 4; ++j) {
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[q][j][r] * sc[j][r] + bi[j][r];
-        if (relu) v[r] = fmaxf(v[r], 0.f);
-      }
+      for (int r = 0; r < 4; ++r) v[r] = acc[q][j][r] * sc[j][r] + bi[j][r];   // the ReLU is applied by the pool phase
       uint2 o;
       o.x = pack_bf16x2(v[0], v[1]);
       o.y = pack_bf16x2(v[2], v[3]);
@@ -135,8 +190,47 @@ __global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const bf16* __restri
     }
   }
   __syncthreads();
+  C1_STAMP(4);
 
   // ---- 3x3 / 2 max-pool out of LDS; one 16-byte channel chunk of one pooled pixel per thread ------------
+  // With the ReLU (the model's case) the pool runs on the bf16 BITS: relu and max commute with the (monotone,
+  // sign-preserving) rounding to bf16, and non-negative bf16 values order like their bit patterns read as int16, while
+  // every negative value (sign bit set) reads as a negative int16: max_i16 over the window and 0 IS relu(max(window)).
+  // Two channels per v_pk_max_i16 instead of two unpacks + two v_max_f32: the pool phase was vector-ALU-bound
+  // (profiles/r02_stem_entry_notes.txt).  A window whose values are all <= 0 gives +0.
+  if (relu) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    for (int id = t; id < TP * WQ * 8; id += 512) {
+      const int c8 = id & 7, pp = id >> 3;
+      const int pyl = pp / WQ, px = pp - pyl * WQ;
+      s16x2 best[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) best[k] = s16x2{0, 0};
+#pragma unroll
+      for (int dr = 0; dr < 3; ++dr) {
+        const int lr = 2 * pyl + dr;
+        if (cr0 + lr < 0) continue;
+#pragma unroll
+        for (int dc = 0; dc < 3; ++dc) {
+          const int cc = 2 * px - 1 + dc;
+          if (cc < 0) continue;
+          const uint4 u = *reinterpret_cast<const uint4*>(smem + (lr * WC + cc) * CO_PITCH + c8 * 16);
+          const unsigned uw[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            s16x2 v;
+            __builtin_memcpy(&v, &uw[k], 4);
+            best[k] = __builtin_elementwise_max(best[k], v);
+          }
+        }
+      }
+      uint4 o;
+      __builtin_memcpy(&o, best, 16);
+      *reinterpret_cast<uint4*>(pooled + (((long)b * HQ + py0 + pyl) * WQ + px) * 64 + c8 * 8) = o;
+    }
+    C1_STAMP(5);
+    return;
+  }
   for (int id = t; id < TP * WQ * 8; id += 512) {
     const int c8 = id & 7, pp = id >> 3;
     const int pyl = pp / WQ, px = pp - pyl * WQ;
@@ -163,12 +257,13 @@ __global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const bf16* __restri
     o.z = pack_bf16x2(best[4], best[5]); o.w = pack_bf16x2(best[6], best[7]);
     *reinterpret_cast<uint4*>(pooled + (((long)b * HQ + py0 + pyl) * WQ + px) * 64 + c8 * 8) = o;
   }
+  C1_STAMP(5);
 }
 
 }  // namespace
 
 int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
-                              int B, int relu, hipStream_t st) {
+                              int B, int relu, int img_f32, hipStream_t st) {
   RVIT_CHECK_ARG(img && w && scale && bias && pooled && B > 0, "stem_conv1_pool: bad arguments");
   RVIT_CHECK_ARG(rvit_aligned16(img) && rvit_aligned16(w) && rvit_aligned16(scale) && rvit_aligned16(bias) &&
                      rvit_aligned16(pooled),
@@ -176,9 +271,21 @@ int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale
   RVIT_CHECK_ARG((long)B * (HQ / TP) < 0x7fffffffL, "stem_conv1_pool: batch too large");
   static_assert(CO_BYTES >= W_BYTES + PATCH_BYTES, "conv-out map must cover the staging area it aliases");
   static RvitLdsLimit lim;
-  if (const int rc = lim.ensure({(const void*)conv1_pool_kernel}, CO_BYTES, "stem_conv1_pool")) return rc;
-  hipLaunchKernelGGL(conv1_pool_kernel, dim3((unsigned)(B * (HQ / TP))), dim3(512), CO_BYTES, st, (const bf16*)img,
-                     (const bf16*)w, scale, bias, (bf16*)pooled, relu);
+  if (const int rc = lim.ensure({(const void*)conv1_pool_kernel<false>, (const void*)conv1_pool_kernel<true>}, CO_BYTES,
+                                "stem_conv1_pool"))
+    return rc;
+  if (img_f32)
+    hipLaunchKernelGGL(conv1_pool_kernel<true>, dim3((unsigned)(B * (HQ / TP))), dim3(512), CO_BYTES, st, img,
+                       (const bf16*)w, scale, bias, (bf16*)pooled, relu);
+  else
+    hipLaunchKernelGGL(conv1_pool_kernel<false>, dim3((unsigned)(B * (HQ / TP))), dim3(512), CO_BYTES, st, img,
+                       (const bf16*)w, scale, bias, (bf16*)pooled, relu);
   RVIT_CHECK_LAUNCH("stem_conv1_pool");
   return RVIT_OK;
 }
+
+#ifdef RVIT_C1_STAMPS
+extern "C" int rvit_debug_c1_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_c1_stamps), (size_t)n * 8);
+}
+#endif

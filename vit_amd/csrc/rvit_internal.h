@@ -47,7 +47,7 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t stream);
 bool rvit_conv3x3_c64_ok(const GemmArgs& a);                  // conv3x3_c64.hip (64 -> 64 channels, weights resident)
 int rvit_conv3x3_c64(const GemmArgs& a, hipStream_t stream);
 int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
-                              int B, int relu, hipStream_t st);  // conv1.hip
+                              int B, int relu, int img_f32, hipStream_t st);  // conv1.hip
 
 // Argument block of the MX-fp8 GEMM (gemm_mx.hip): C = act(A_q . B_q^T + bias) + R, optional MX copy of C.
 struct MxGemmArgs {

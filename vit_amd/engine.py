@@ -173,10 +173,11 @@ class Engine:
         return b
 
     # ---- forward -------------------------------------------------------------------------------
-    def _stem(self, P, b, B) -> torch.Tensor:
+    def _stem(self, P, b, B, xin) -> torch.Tensor:
         c1 = P["conv1"]
-        # conv7x7/2 + folded BN + ReLU + max-pool in one kernel: the 112x112x64 map stays on chip
-        cur = ops.stem_conv1_pool(b["img"], c1["w232"], c1["scale"], c1["bias"], b["s1a"])
+        # conv7x7/2 + folded BN + ReLU + max-pool in one kernel, read straight from the fp32 NCHW input: neither the
+        # 112x112x64 map nor a packed copy of the image ever reaches HBM
+        cur = ops.stem_conv1_pool_f32(xin, c1["w232"], c1["scale"], c1["bias"], b["s1a"])
         stage, free = 1, ["b", "c", "d"]
         for blk in P["blocks"]:
             stride = blk["c1"]["stride"]
@@ -245,8 +246,7 @@ class Engine:
         xs = b["x"]
         x2 = xs.view(T, E)
         if m.cnn_backbone is not None:
-            ops.input_pack(xin, b["img"], 3, 3)
-            feat = self._stem(P, b, B)  # [B,7,7,512]
+            feat = self._stem(P, b, B, xin)  # [B,7,7,512]
             ops.gemm(feat.view(B * m.num_patches, -1), P["pe_w"], x2, bias=P["pe_b"], residual=P["pos"][1:],
                      residual_period=m.num_patches, row_group=m.num_patches, row_extra=1)
         else:

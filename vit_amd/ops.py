@@ -313,6 +313,24 @@ def stem_conv1_pool(img: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bia
     return pooled
 
 
+def stem_conv1_pool_f32(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, pooled: torch.Tensor,
+                        relu: bool = True) -> torch.Tensor:
+    """stem_conv1_pool straight from the fp32 NCHW input x [B,3,224,224]: no packed copy of the image in HBM."""
+    _need_cuda(x, w, scale, bias, pooled)
+    B = x.shape[0]
+    if tuple(x.shape) != (B, 3, 224, 224) or x.dtype != torch.float32 or not x.is_contiguous() \
+            or pooled.shape != (B, 56, 56, 64) or w.shape != (64, 232) or w.dtype != BF16 or pooled.dtype != BF16 \
+            or not (w.is_contiguous() and pooled.is_contiguous()):
+        raise ValueError("stem_conv1_pool_f32: x f32 [B,3,224,224], w bf16 [64,232], pooled bf16 [B,56,56,64], contiguous")
+    _vec_f32(scale, 64, "stem_conv1_pool_f32: scale")
+    _vec_f32(bias, 64, "stem_conv1_pool_f32: bias")
+    with _Span("stem_conv1_pool", 2 * B * 112 * 112 * 64 * 147, _nbytes(x, w, pooled)):
+        check(_lib.load().rvit_stem_conv1_pool_f32_fwd(x.data_ptr(), w.data_ptr(), scale.data_ptr(), bias.data_ptr(),
+                                                       pooled.data_ptr(), B, int(relu), _stream()),
+              "rvit_stem_conv1_pool_f32_fwd")
+    return pooled
+
+
 def input_pack(x: torch.Tensor, out: torch.Tensor, pad_top: int, pad_left: int) -> torch.Tensor:
     """x fp32 [B,C<=3,H,W] -> interior of the zero-haloed bf16 NHWC4 buffer out [B,Hp,Wp,4]."""
     _need_cuda(x, out)
