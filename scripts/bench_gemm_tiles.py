@@ -25,9 +25,11 @@ def timeit(fn, n=20):
 
 
 T, TB = 512 * 50, 256 * 197
-gemms = [("R qkv", T, 768, 256), ("R fc1", T, 1024, 256), ("R fc2", T, 256, 1024),
+gemms = [("R qkv", T, 768, 256), ("R out", T, 256, 256), ("R fc1", T, 1024, 256), ("R fc2", T, 256, 1024),
          ("vitB qkv", TB, 2304, 768), ("vitB out", TB, 768, 768), ("vitB fc1", TB, 3072, 768), ("vitB fc2", TB, 768, 3072),
          ("vitL fc1", TB, 4096, 1024), ("big 4096^3", 4096, 4096, 4096), ("big 8192^3", 8192, 8192, 8192)]
+if os.environ.get("ONLY"):
+    gemms = [g for g in gemms if g[0].startswith(os.environ["ONLY"])]
 for name, M, N, K in gemms:
     a = torch.randn(M, K, device=dev).to(bf)
     w = (torch.randn(N, K, device=dev) * 0.05).to(bf)

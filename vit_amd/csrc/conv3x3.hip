@@ -10,9 +10,9 @@
 // the fragment row index; only the 8 KB weight tile of each tap streams through a 2-stage ring.
 //
 // Geometry.  Output pixels are numbered m = (b*H + h)*W + w; a workgroup owns BM consecutive m and
-// 64 output channels.  In "padded row" space R = b*(H+2) + h + 1 every image carries its own zero
-// rows, so tap (kh,kw) of output (R, w) reads padded pixel (R + kh - 1, w + kw) and never leaves
-// the image.  The patch holds padded rows R_first-1 .. R_last+1, all W+2 columns, 128 B (64 bf16)
+// 64 output channels.  In "padded row" space R = b*(H+1) + h + 1 a zero row sits above every image (and
+// below the last one; the row below image b IS the row above image b+1), so tap (kh,kw) of output (R, w) reads
+// padded pixel (R + kh - 1, w + kw) and never reaches another image's pixels.  The patch holds padded rows R_first-1 .. R_last+1, all W+2 columns, 128 B (64 bf16)
 // per pixel; a pixel outside the image is DMA'd from a 16-byte zero page.  LDS row index of the
 // fragment row of output m for tap (kh,kw):  pb(m) + kh*(W+2) + kw,  pb = (R - R_first)*(W+2) + w.
 // The 16-byte chunk index inside a patch row is XOR-swizzled with row & 6 on the DMA source and on the
@@ -165,7 +165,10 @@ __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2)
   char* const bring = smem + (DB ? 2 : 1) * patch_bytes;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int H = p.H, W = p.W, Cin = p.Cpix, PW = W + 2, HP = H + 2;
+  // HP = H + 1: ONE zero row between consecutive images (the bottom pad of image b is the top pad of image b + 1:
+  // both are zero, and a tap never looks further than one row), which trims a row of every patch that crosses an
+  // image boundary (layer2: 450 -> 420 patch pixels, layer4: 468 -> 414)
+  const int H = p.H, W = p.W, Cin = p.Cpix, PW = W + 2, HP = H + 1;
   const int flip = p.transposed;
 
   // XCD-aware tile id (as gemm.hip): n tiles of one m tile are adjacent and share an XCD's L2
@@ -394,7 +397,7 @@ static int c3_tile_rows(int H, int W) {
 static int c3_patch_pixels(int H, int W) {
   const int tr = c3_tile_rows(H, W);
   if (tr > 0) return (tr + 2) * (W + 2);
-  const int rows = (C3_BM - 1 + W - 1) / W + 2 * ((C3_BM - 1) / (H * W) + 1) + 3;
+  const int rows = (C3_BM - 1 + W - 1) / W + ((C3_BM - 1) / (H * W) + 1) + 3;   // one shared zero row per image boundary
   return rows * (W + 2);
 }
 
@@ -470,7 +473,11 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
   // channels (a property of the layer, never of the batch size), tile 15 forces it.
   const bool c256_ok = (a.N & 255) == 0 && patch_bytes + 2 * 256 * 128 <= 160 * 1024;
   if (variant == 5) RVIT_CHECK_ARG(c256_ok, "conv3x3: the 256-channel variant does not fit this geometry");
-  if (variant == 5 || (variant == 0 && c256_ok && a.Cpix >= 512)) return c3_launch<256, false, 16>(a, patch_bytes, tile_len, st);
+  if (variant == 5 || (variant == 0 && c256_ok && a.Cpix >= 512)) {
+    // a third ring stage where it fits (layer4: 53 + 96 KB): -2 % (108.6 -> 106.1 us at B = 512), same bits
+    if (patch_bytes + 3 * 256 * 128 <= 160 * 1024) return c3_launch<256, false, 16, 3>(a, patch_bytes, tile_len, st);
+    return c3_launch<256, false, 16>(a, patch_bytes, tile_len, st);
+  }
   return wide ? c3_launch<128, true, 8>(a, patch_bytes, tile_len, st) : c3_launch<64, false, 8>(a, patch_bytes, tile_len, st);
 }
 
