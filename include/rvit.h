@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 11
+#define RVIT_ABI_VERSION 12
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -214,6 +214,26 @@ int rvit_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gam
  * q: e4m3 [rows, ldq]; scales: E8M0, tiled as for rvit_quantize_mxfp8. */
 int rvit_layernorm_mxfp8_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta,
                              uint8_t* q, int64_t ldq, uint8_t* scales, int64_t rows, int E, float eps, void* stream);
+
+/* Feed-forward half of a pre-LN encoder layer for inference, in place on the fp32 residual stream:
+ *   x += linear2(gelu(linear1(LayerNorm(x))))     (torch transformer.py:949-950, 980-982; erf GELU)
+ * in ONE kernel: a workgroup keeps its tokens' LayerNorm output and GELU map in LDS, so the hidden map never
+ * reaches HBM.  Same bits as rvit_layernorm_fwd -> rvit_gemm_bf16(gelu) -> rvit_gemm_bf16(residual).
+ *   x: f32 [T, E], E == 256; gamma/beta: f32 [E]; w1: bf16 [hidden, E], b1: f32 [hidden]; w2: bf16 [E, hidden],
+ *   b2: f32 [E]; hidden % 256 == 0.  rows_per_wg: tokens per workgroup, 0 = chosen from T (<= 112). */
+int rvit_encoder_mlp_fwd(float* x, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
+                         const void* w2, const float* b2, int64_t T, int E, int hidden, int rows_per_wg,
+                         void* stream);
+
+/* Self-attention half of a pre-LN encoder layer for inference, in place on the fp32 residual stream:
+ *   x += out_proj(softmax(q k^T / 8) v),  q | k | v = in_proj(LayerNorm(x))
+ * (torch transformer.py:947-948; functional.py:5819-5833, 6569-6637), in ONE kernel: a workgroup owns two images,
+ * q, k, v, the probabilities and the attention output never leave the CU.
+ *   x: f32 [B*S, E], E == 256, H == 4 (head_dim 64), S <= 64; gamma/beta: f32 [E];
+ *   wqkv: bf16 [3E, E] (in_proj_weight), bqkv: f32 [3E]; wout: bf16 [E, E], bout: f32 [E]. */
+int rvit_encoder_attn_fwd(float* x, const float* gamma, const float* beta, float eps, const void* wqkv,
+                          const float* bqkv, const void* wout, const float* bout, int B, int S, int E, int H,
+                          void* stream);
 
 /* LayerNorm backward fused with the residual-gradient accumulation of the pre-LN block
  * (x + f(LN(x)), torch transformer.py:947-950):  dx (+)= LN'(dy); dgamma += ..., dbeta += ...

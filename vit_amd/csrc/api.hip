@@ -294,6 +294,18 @@ int rvit_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gam
                                  rows, E, eps, (hipStream_t)stream);
 }
 
+int rvit_encoder_mlp_fwd(float* x, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
+                         const void* w2, const float* b2, int64_t T, int E, int hidden, int rows_per_wg,
+                         void* stream) {
+  return rvit_encoder_mlp_impl(x, gamma, beta, eps, w1, b1, w2, b2, T, E, hidden, rows_per_wg, (hipStream_t)stream);
+}
+
+int rvit_encoder_attn_fwd(float* x, const float* gamma, const float* beta, float eps, const void* wqkv,
+                          const float* bqkv, const void* wout, const float* bout, int B, int S, int E, int H,
+                          void* stream) {
+  return rvit_encoder_attn_impl(x, gamma, beta, eps, wqkv, bqkv, wout, bout, B, S, E, H, (hipStream_t)stream);
+}
+
 int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
                        void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* stream) {

@@ -81,11 +81,47 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LayerNorm row arithmetic with explicit roundings (no floating-point contraction): every kernel that normalises a
+// row (norm.hip, encoder.hip) produces the same bits, whatever the compiler would have fused in its context.
+__device__ __forceinline__ float ln_mean(float sum, float inv_e) { return __fmul_rn(sum, inv_e); }
+__device__ __forceinline__ float ln_sq(float q, float d) { return __fmaf_rn(d, d, q); }
+__device__ __forceinline__ float ln_rstd(float sq_sum, float inv_e, float eps) {
+  return 1.0f / sqrtf(__fadd_rn(__fmul_rn(sq_sum, inv_e), eps));
+}
+__device__ __forceinline__ float ln_affine(float d, float rstd, float g, float b) {
+  return __fmaf_rn(__fmul_rn(d, rstd), g, b);
+}
+
 // erf-form GELU (torch nn.GELU(approximate='none'), activation='gelu').  The library erff costs ~45 vector-ALU
 // instructions per element (two branches, both taken by a wave): in the fc1 epilogue that was 60-110 us of a 300 us
-// GEMM.  Here Phi(x) = 0.5 (1 + erf(x / sqrt 2)) comes from the rational approximation 7.1.26 of Abramowitz & Stegun,
-// |error in erf| <= 1.5e-7 (the size of an fp32 rounding; outputs and saved activations are bf16, 2^-9 relative),
-// branch-free: one v_rcp_f32, one v_exp_f32, six fused multiply-adds.  tail = 1 - Phi(|x|).
+// GEMM.
+// Forward: gelu(x) = x/2 (1 + erf(x / sqrt 2)) with erf(x / sqrt 2) = xc P(xc^2), xc = x clamped to +-3.5 sqrt 2
+// (1 - erf(3.5) = 7e-7), P the degree-12 Chebyshev interpolant of erf(sqrt(u)/sqrt 2)/sqrt(u) on [0, 24.5] evaluated
+// by Horner in t = 2u/24.5 - 1 (|coefficients| <= 0.29: no cancellation).  |error in Phi| <= 3e-7 in fp32 (outputs
+// are bf16, 2^-9 relative).  No transcendental instruction: 17 multiply-adds that the compiler issues as packed
+// v_pk_fma_f32 pairs, ~40 cycles per wave and element against ~95 for the rational form with v_exp_f32 + v_rcp_f32
+// (7.1.26 of Abramowitz & Stegun, below), which in the fused encoder kernel was more vector-ALU time than the MFMA
+// time of the two GEMMs around it.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float xc = fminf(fmaxf(x, -4.94974756f), 4.94974756f);
+  const float t = fmaf(xc * xc, 0.0816326514f, -1.0f);
+  float p = fmaf(t, 1.212488976e-03f, -2.922325628e-03f);
+  p = fmaf(p, t, 2.721123397e-03f);
+  p = fmaf(p, t, -4.854901228e-03f);
+  p = fmaf(p, t, 1.249409094e-02f);
+  p = fmaf(p, t, -2.146489173e-02f);
+  p = fmaf(p, t, 3.163446859e-02f);
+  p = fmaf(p, t, -4.571118578e-02f);
+  p = fmaf(p, t, 6.254854053e-02f);
+  p = fmaf(p, t, -8.105718344e-02f);
+  p = fmaf(p, t, 1.037653387e-01f);
+  p = fmaf(p, t, -1.419164836e-01f);
+  p = fmaf(p, t, 2.855813503e-01f);
+  const float hx = 0.5f * x;
+  return fmaf(hx, xc * p, hx);
+}
+// Backward: Phi and phi from 7.1.26 of Abramowitz & Stegun (|error in erf| <= 1.5e-7), branch-free: one v_rcp_f32,
+// one v_exp_f32, six fused multiply-adds.  tail = 1 - Phi(|x|).
 __device__ __forceinline__ float gelu_tail(float ax, float e) {  // e = exp(-x^2 / 2)
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
   float q = fmaf(t, 1.061405429f, -1.453152027f);
@@ -93,11 +129,6 @@ __device__ __forceinline__ float gelu_tail(float ax, float e) {  // e = exp(-x^2
   q = fmaf(q, t, -0.284496736f);
   q = fmaf(q, t, 0.254829592f);
   return 0.5f * q * t * e;
-}
-__device__ __forceinline__ float gelu_erf(float x) {
-  const float ax = fabsf(x);
-  const float tail = gelu_tail(ax, __expf(-0.5f * x * x));
-  return x >= 0.f ? fmaf(-x, tail, x) : x * tail;  // x Phi(x); Phi(-a) = tail(a)
 }
 // d/dx gelu_erf = Phi(x) + x phi(x)
 __device__ __forceinline__ float gelu_erf_grad(float x) {

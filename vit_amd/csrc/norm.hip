@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
     }
   }
   const float inv_e = 1.0f / (float)E;
-  const float mean = wave_sum(s) * inv_e;
+  const float mean = ln_mean(wave_sum(s), inv_e);
   float q = 0.f;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
@@ -50,13 +50,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
     if (e < E) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float d = v[it][k] - mean;
-        q += d * d;
+        v[it][k] = __fsub_rn(v[it][k], mean);
+        q = ln_sq(q, v[it][k]);
       }
     }
   }
-  const float var = wave_sum(q) * inv_e;
-  const float rstd = 1.0f / sqrtf(var + eps);
+  const float rstd = ln_rstd(wave_sum(q), inv_e, eps);
   if (lane == 0) {
     if (mean_out) mean_out[row] = mean;
     if (rstd_out) rstd_out[row] = rstd;
@@ -67,10 +66,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const void* __restri
     if (e < E) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + e);
       const float4 b = *reinterpret_cast<const float4*>(beta + e);
-      const float o0 = (v[it][0] - mean) * rstd * g.x + b.x;
-      const float o1 = (v[it][1] - mean) * rstd * g.y + b.y;
-      const float o2 = (v[it][2] - mean) * rstd * g.z + b.z;
-      const float o3 = (v[it][3] - mean) * rstd * g.w + b.w;
+      const float o0 = ln_affine(v[it][0], rstd, g.x, b.x);
+      const float o1 = ln_affine(v[it][1], rstd, g.y, b.y);
+      const float o2 = ln_affine(v[it][2], rstd, g.z, b.z);
+      const float o3 = ln_affine(v[it][3], rstd, g.w, b.w);
       if constexpr (OUT_F32) {
         *reinterpret_cast<float4*>((float*)y + row * ldy + e) = make_float4(o0, o1, o2, o3);
       } else {
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(256) void layernorm_mx_fwd_kernel(const void* __res
     }
   }
   const float inv_e = 1.0f / (float)E;
-  const float mean = wave_sum(s) * inv_e;
+  const float mean = ln_mean(wave_sum(s), inv_e);
   float qq = 0.f;
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
@@ -117,13 +116,12 @@ __global__ __launch_bounds__(256) void layernorm_mx_fwd_kernel(const void* __res
     if (e < E) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float d = v[it][k] - mean;
-        qq += d * d;
+        v[it][k] = __fsub_rn(v[it][k], mean);
+        qq = ln_sq(qq, v[it][k]);
       }
     }
   }
-  const float var = wave_sum(qq) * inv_e;
-  const float rstd = 1.0f / sqrtf(var + eps);
+  const float rstd = ln_rstd(wave_sum(qq), inv_e, eps);
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int e = it * 256 + lane * 4;
@@ -132,8 +130,8 @@ __global__ __launch_bounds__(256) void layernorm_mx_fwd_kernel(const void* __res
     if (ok) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + e);
       const float4 b = *reinterpret_cast<const float4*>(beta + e);
-      const uint32_t p0 = pack_bf16x2((v[it][0] - mean) * rstd * g.x + b.x, (v[it][1] - mean) * rstd * g.y + b.y);
-      const uint32_t p1 = pack_bf16x2((v[it][2] - mean) * rstd * g.z + b.z, (v[it][3] - mean) * rstd * g.w + b.w);
+      const uint32_t p0 = pack_bf16x2(ln_affine(v[it][0], rstd, g.x, b.x), ln_affine(v[it][1], rstd, g.y, b.y));
+      const uint32_t p1 = pack_bf16x2(ln_affine(v[it][2], rstd, g.z, b.z), ln_affine(v[it][3], rstd, g.w, b.w));
       o[0] = bf16_lo(p0); o[1] = bf16_hi(p0); o[2] = bf16_lo(p1); o[3] = bf16_hi(p1);
     }
     float amax = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));

@@ -127,6 +127,11 @@ int rvit_layernorm_mx_fwd_impl(const void* x, int x_f32, long ldx, const float* 
 int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                             const float* gamma, float* dxs, long lddx, int accumulate, void* dx_bf16, long lddb,
                             float* dgamma, float* dbeta, long rows, int E, hipStream_t st);
+int rvit_encoder_mlp_impl(float* x, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
+                          const void* w2, const float* b2, long T, int E, int hidden, int rows_per_wg, hipStream_t st);
+int rvit_encoder_attn_impl(float* x, const float* gamma, const float* beta, float eps, const void* wqkv,
+                           const float* bqkv, const void* wout, const float* bout, int B, int S, int E, int H,
+                           hipStream_t st);
 int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
                        float drop_p, uint64_t drop_seed, hipStream_t st);
 int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,

@@ -13,6 +13,7 @@ applied in the conv epilogue; biases / LN affine / pos_embed stay fp32.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -54,6 +55,8 @@ class Engine:
         # (e4m3 + E8M0 per 32) weights and activations; LayerNorm, softmax, the residual stream, the stem, the
         # patch embedding and the head stay bf16 / fp32 (BASELINE.json configs[4])
         self.precision = "bf16"
+        # fused encoder-layer kernels where the shape allows (RVIT_ENCODER_FUSED=0: the per-op path, for A/B runs)
+        self.fused_encoder = os.environ.get("RVIT_ENCODER_FUSED", "1") != "0"
         self.graph_max_batch = 0
 
     def set_precision(self, precision: str) -> None:
@@ -221,13 +224,21 @@ class Engine:
                         out_s=b["hid_s"])
             ops.gemm_mx(b["hid_q"], b["hid_s"], L["fc2_w_q"], L["fc2_w_s"], x2, bias=L["fc2_b"], residual=x2)
             return
-        ops.layernorm(x2, L["ln1_w"], L["ln1_b"], b["ln"], L["eps1"])
-        ops.gemm(b["ln"], L["qkv_w"], b["qkv"], bias=L["qkv_b"])
-        ops.attention(b["qkv"], b["att"], B, S, H)
-        ops.gemm(b["att"], L["out_w"], x2, bias=L["out_b"], residual=x2)
-        ops.layernorm(x2, L["ln2_w"], L["ln2_b"], b["ln"], L["eps2"])
-        ops.gemm(b["ln"], L["fc1_w"], b["hid"], bias=L["fc1_b"], act="gelu")
-        ops.gemm(b["hid"], L["fc2_w"], x2, bias=L["fc2_b"], residual=x2)
+        # E = 256: each half of the layer is ONE kernel that keeps its tokens on the CU from the LayerNorm to the
+        # residual add (csrc/encoder.hip); the choice depends on the model's shape only, never on the batch
+        if self.fused_encoder and ops.encoder_attn_supported(E, H, S):
+            ops.encoder_attn(x2, L["ln1_w"], L["ln1_b"], L["qkv_w"], L["qkv_b"], L["out_w"], L["out_b"], B, S, H, L["eps1"])
+        else:
+            ops.layernorm(x2, L["ln1_w"], L["ln1_b"], b["ln"], L["eps1"])
+            ops.gemm(b["ln"], L["qkv_w"], b["qkv"], bias=L["qkv_b"])
+            ops.attention(b["qkv"], b["att"], B, S, H)
+            ops.gemm(b["att"], L["out_w"], x2, bias=L["out_b"], residual=x2)
+        if self.fused_encoder and ops.encoder_mlp_supported(E, L["fc1_w"].shape[0]):
+            ops.encoder_mlp(x2, L["ln2_w"], L["ln2_b"], L["fc1_w"], L["fc1_b"], L["fc2_w"], L["fc2_b"], L["eps2"])
+        else:
+            ops.layernorm(x2, L["ln2_w"], L["ln2_b"], b["ln"], L["eps2"])
+            ops.gemm(b["ln"], L["fc1_w"], b["hid"], bias=L["fc1_b"], act="gelu")
+            ops.gemm(b["hid"], L["fc2_w"], x2, bias=L["fc2_b"], residual=x2)
 
     @torch.no_grad()
     def infer(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:

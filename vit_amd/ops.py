@@ -457,6 +457,64 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, lse:
     return out
 
 
+def encoder_mlp(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor,
+                w2: torch.Tensor, b2: torch.Tensor, eps: float = 1e-5, rows_per_wg: int = 0) -> torch.Tensor:
+    """x += linear2(gelu(linear1(LayerNorm(x)))) in place; x f32 [T,256] contiguous, w1 bf16 [hidden,256],
+    w2 bf16 [256,hidden]: one kernel, the hidden map stays in LDS (inference)."""
+    _need_cuda(x, gamma, beta, w1, b1, w2, b2)
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("encoder_mlp: x must be a contiguous float32 [T, E] tensor")
+    T, E = x.shape
+    hidden = w1.shape[0]
+    if not encoder_mlp_supported(E, hidden):
+        raise ValueError(f"encoder_mlp: E={E} / hidden={hidden} not supported (E == 256, hidden % 256 == 0)")
+    if w1.dtype != BF16 or w2.dtype != BF16 or tuple(w1.shape) != (hidden, E) or tuple(w2.shape) != (E, hidden) \
+            or not w1.is_contiguous() or not w2.is_contiguous():
+        raise ValueError("encoder_mlp: w1 [hidden,E] / w2 [E,hidden] must be contiguous bf16")
+    _vec_f32(gamma, E, "encoder_mlp: gamma")
+    _vec_f32(beta, E, "encoder_mlp: beta")
+    _vec_f32(b1, hidden, "encoder_mlp: b1")
+    _vec_f32(b2, E, "encoder_mlp: b2")
+    with _Span("encoder_mlp", 4 * T * E * hidden, 8 * T * E + 4 * E * hidden):
+        check(_lib.load().rvit_encoder_mlp_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), w1.data_ptr(),
+                                               b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), T, E, hidden,
+                                               int(rows_per_wg), _stream()), "rvit_encoder_mlp_fwd")
+    return x
+
+
+def encoder_attn(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wqkv: torch.Tensor, bqkv: torch.Tensor,
+                 wout: torch.Tensor, bout: torch.Tensor, B: int, S: int, H: int, eps: float = 1e-5) -> torch.Tensor:
+    """x += out_proj(attention(in_proj(LayerNorm(x)))) in place; x f32 [B*S,256] contiguous, wqkv bf16 [768,256],
+    wout bf16 [256,256]: one kernel, q/k/v and the attention output stay in LDS (inference)."""
+    _need_cuda(x, gamma, beta, wqkv, bqkv, wout, bout)
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[0] != B * S:
+        raise ValueError("encoder_attn: x must be a contiguous float32 [B*S, E] tensor")
+    E = x.shape[1]
+    if not encoder_attn_supported(E, H, S):
+        raise ValueError(f"encoder_attn: E={E} H={H} S={S} not supported (E == 256, H == 4, S <= 64)")
+    if wqkv.dtype != BF16 or wout.dtype != BF16 or tuple(wqkv.shape) != (3 * E, E) or tuple(wout.shape) != (E, E) \
+            or not wqkv.is_contiguous() or not wout.is_contiguous():
+        raise ValueError("encoder_attn: wqkv [3E,E] / wout [E,E] must be contiguous bf16")
+    _vec_f32(gamma, E, "encoder_attn: gamma")
+    _vec_f32(beta, E, "encoder_attn: beta")
+    _vec_f32(bqkv, 3 * E, "encoder_attn: bqkv")
+    _vec_f32(bout, E, "encoder_attn: bout")
+    T = B * S
+    with _Span("encoder_attn", 2 * T * E * 4 * E + 4 * B * H * S * S * 64, 8 * T * E + 8 * E * E):
+        check(_lib.load().rvit_encoder_attn_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps), wqkv.data_ptr(),
+                                                bqkv.data_ptr(), wout.data_ptr(), bout.data_ptr(), B, S, E, H, _stream()),
+              "rvit_encoder_attn_fwd")
+    return x
+
+
+def encoder_attn_supported(E: int, H: int, S: int) -> bool:
+    return E == 256 and H == 4 and 1 <= S <= 64
+
+
+def encoder_mlp_supported(E: int, hidden: int) -> bool:
+    return E == 256 and hidden > 0 and hidden % 256 == 0
+
+
 # =================================================================================================
 # backward / loss kernels
 # =================================================================================================
