@@ -343,7 +343,12 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   // enough tiles for whole rounds over the 256 CUs and, with few rounds, a long K loop to pay for the un-overlapped
   // prologue / epilogue of a workgroup that has the CU to itself.
   const long t256 = ((a.M + 255) / 256) * (long)((a.N + 255) / 256);
-  const bool big = a.mode == 0 && a.K >= 512 && t256 >= 512 && (t256 >= 1024 || a.K >= 2048);
+  const bool big_plain = a.mode == 0 && a.K >= 512 && t256 >= 512 && (t256 >= 1024 || a.K >= 2048);
+  // implicit-GEMM convs (the stride-2 3x3 convs of the stem): the gathered A tile is re-fetched once per 64 output
+  // columns, so the wide tile pays off earlier: B=512 layer3.0.conv1 97.5 -> 82 us, layer4.0.conv1 93 -> 66 us; at 98
+  // tiles (layer4, B=256) the chip is too empty and 256x64 wins again (profiles/r02_stride2_tiles.txt).  Same bits.
+  const bool big_conv = a.mode == 1 && !a.transposed && (a.N & 255) == 0 && a.K >= 1024 && t256 >= 192;
+  const bool big = big_plain || big_conv;
   int cfg;
   if (forced) cfg = forced;
   else if (big) cfg = 4;
