@@ -459,7 +459,9 @@ int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float*
 int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
                        float drop_p, uint64_t drop_seed, hipStream_t st) {
   RVIT_CHECK_ARG(qkv && out, "attn_fwd: null pointer");
-  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (long)B * H * S * S < 0xffffffffL, "attn_fwd: bad dropout arguments");
+  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "attn_fwd: drop_p must be in [0, 1)");
+  // the dropout element index is 32 bits wide; without dropout there is no such limit on the batch
+  RVIT_CHECK_ARG(drop_p == 0.f || (long)B * H * S * S < 0xffffffffL, "attn_fwd: dropout element index exceeds 32 bits");
   const DropKey dk = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_fwd: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
   RVIT_CHECK_ARG(ldq >= 3L * H * 64 && (ldq & 7) == 0 && ldo >= (long)H * 64 && (ldo & 3) == 0,
@@ -485,7 +487,8 @@ int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const flo
                        long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,
                        hipStream_t st) {
   RVIT_CHECK_ARG(qkv && O && dO && lse && dqkv, "attn_bwd: null pointer");
-  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (long)B * H * S * S < 0xffffffffL, "attn_bwd: bad dropout arguments");
+  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "attn_bwd: drop_p must be in [0, 1)");
+  RVIT_CHECK_ARG(drop_p == 0.f || (long)B * H * S * S < 0xffffffffL, "attn_bwd: dropout element index exceeds 32 bits");
   const DropKey dk = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_bwd: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
   RVIT_CHECK_ARG(ldq >= 3L * H * 64 && lddq >= 3L * H * 64 && ldo >= (long)H * 64 && lddo >= (long)H * 64 &&
