@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 12
+#define RVIT_ABI_VERSION 13
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -252,6 +252,15 @@ int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx
  *   ((b*H + h)*S + query)*S + key. */
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
                   float drop_p, uint64_t drop_seed, void* stream);
+
+/* rvit_attn_fwd for the MX-fp8 inference mode (BASELINE.json configs[4]): both products run on the fp8 MFMA and the
+ * result is emitted as the MXFP8 operand of the out_proj GEMM (no bf16 attention map, no quantisation pass).
+ *   qkv: bf16 [B*S, ldq] as for rvit_attn_fwd; q and k are quantised to e4m3 with one power-of-two scale per
+ *   (token, head) row, v with one per (image, head), the probabilities as e4m3(256 p);
+ *   out_q: e4m3 [B*S, ldo]; out_s: E8M0 scales of a [B*S, H*64] operand, tiled as for rvit_quantize_mxfp8
+ *   (H even: K % 128 == 0).  The reference has no fp8 path; oracle/ref_mxfp8.py restates this arithmetic. */
+int rvit_attn_fwd_fp8(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out_s, int B, int S, int H, int64_t ldq,
+                      float scale, void* stream);
 
 /* Backward of rvit_attn_fwd: dqkv (same layout as qkv) from qkv, out, dout and the saved lse;
  * (drop_p, drop_seed) must be the forward's. */

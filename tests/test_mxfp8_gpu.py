@@ -227,3 +227,42 @@ def test_layernorm_mx_equals_layernorm_then_quantize(dev, rows, E, dtype):
     assert torch.equal(s, s_ref)
     with pytest.raises(ValueError):
         ops.layernorm_mx(x[:, :96], gamma[:96], beta[:96], q[:, :96], s, 1e-6)
+
+
+@pytest.mark.parametrize("B,S,H", [(3, 50, 4), (2, 197, 16), (1, 256, 2), (2, 33, 2), (5, 1, 2)])
+def test_attention_fp8_matches_emulation(dev, B, S, H):
+    """rvit_attn_fwd_fp8 (both products on the fp8 MFMA, MXFP8 output) against oracle/ref_mxfp8.attention_fp8 on the
+    same bf16 qkv.  The two sides quantise identically (power-of-two scales are exact); what differs is v_exp_f32
+    against torch.exp2 and the fp32 summation order, so a probability (e4m3: 6-12 % steps) or an output element can
+    round the other way now and then (measured: 0.2-0.4 % of the elements differ).  Stated tolerance on the
+    dequantised output: at most 3 % of the elements differ at all, none by more than two e4m3 steps of its MX block
+    (2^-2 of the block maximum: one step, or a block whose maximum crossed a power of two and took the next scale),
+    mean |diff| <= 2e-3 of the mean magnitude."""
+    from oracle.ref_mxfp8 import attention_fp8, mx_fake_quant
+    from vit_amd import ops
+    E = H * 64
+    g = torch.Generator().manual_seed(B * 1000 + S + H)
+    qkv = (torch.randn(B * S, 3 * E, generator=g) * torch.exp(0.5 * torch.randn(B * S, 1, generator=g))).to(torch.bfloat16)
+    qkv[:, 2 * E:] *= 0.5
+    oq = torch.zeros(B * S, E, dtype=torch.uint8, device=dev)
+    os_ = torch.zeros(ops.mx_scale_shape(B * S, E), dtype=torch.uint8, device=dev)
+    ops.attention_fp8(qkv.to(dev), oq, os_, B, S, H)
+    got = mx_dequant(oq, os_)
+    q, k, v = (u.float().view(B, S, H, 64).transpose(1, 2) for u in qkv.chunk(3, dim=-1))
+    o = attention_fp8(q, k, v).transpose(1, 2).reshape(B * S, E)
+    want = mx_fake_quant(o.to(torch.bfloat16).float())
+    d = (got - want).abs()
+    blk = want.reshape(B * S, E // 32, 32).abs().amax(dim=2, keepdim=True).expand(-1, -1, 32).reshape(B * S, E)
+    frac = (d > 0).float().mean().item()
+    print(f"B={B} S={S} H={H}: differing {frac:.4f}, max diff / block max {(d / blk.clamp(min=1e-30)).max():.4f}, "
+          f"mean |diff| {d.mean():.3g} of mean |o| {want.abs().mean():.3g}")
+    assert torch.isfinite(got).all()
+    assert frac <= 0.03
+    assert (d <= blk * 2.0 ** -2 + 1e-30).all()
+    assert d.mean().item() <= 2e-3 * want.abs().mean().item()
+    # and it is attention: close to the fp32 softmax(q k^T / 8) v within the format's cost (measured 0.067-0.082 on
+    # these random operands, where the output is a near-uniform average of S random rows and therefore small)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B * S, E)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    print(f"   relative L2 against fp32 attention {rel:.4f}")
+    assert rel <= 0.11

@@ -306,6 +306,11 @@ int rvit_encoder_attn_fwd(float* x, const float* gamma, const float* beta, float
   return rvit_encoder_attn_impl(x, gamma, beta, eps, wqkv, bqkv, wout, bout, B, S, E, H, (hipStream_t)stream);
 }
 
+int rvit_attn_fwd_fp8(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out_s, int B, int S, int H, int64_t ldq,
+                      float scale, void* stream) {
+  return rvit_attn_fwd_fp8_impl(qkv, out_q, ldo, out_s, B, S, H, ldq, scale, (hipStream_t)stream);
+}
+
 int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
                        void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* stream) {

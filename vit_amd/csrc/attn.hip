@@ -11,6 +11,7 @@
 // transposing LDS read.  The whole key range fits in registers (S <= 256), so no online rescale.
 #include "common.h"
 #include "rvit_internal.h"
+#include "mx_common.h"
 
 namespace {
 
@@ -182,6 +183,219 @@ int launch_attn_fwd(const bf16* qkv, bf16* out, float* lse, int B, int S, int H,
   return RVIT_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fp8 attention for the MX-fp8 inference mode (BASELINE.json configs[4]: "fp8 MFMA attention + MLP"): the same
+// dataflow as attn_fwd_kernel with both products on v_mfma_f32_32x32x16_fp8_fp8 and the output emitted directly as
+// MXFP8 (the operand of the out_proj's rvit_gemm_mxfp8), so the bf16 attention map and its quantisation pass
+// disappear.  q, k, v arrive as the bf16 in_proj output and are quantised to e4m3 while they are staged:
+//   k: one power-of-two scale per (key, head) row of 64 (E8M0 rule of mx_common.h: 2^(floor(log2 amax) - 8));
+//   q: the same per (query, head) row, in the wave that owns the query;
+//   v: one scale per (image, head) (its contraction axis is the key axis, so a per-row scale could not be factored
+//      out of the P V sum), stored TRANSPOSED in LDS as bytes, V^T[d][key];
+//   p: exp2(..) in (0, 1] times 256, rounded to e4m3 (the row sum uses the unrounded values).
+// scores = (q8 . k8) * sq * sk in fp32; O = (P8 . V8) * sv / (256 * sum), rounded to bf16 (the per-op path's storage
+// point), then MX-quantised per 32 columns.  oracle/ref_mxfp8.py (fp8_attention=True) restates exactly this.
+template <int NKB>
+__global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(const bf16* __restrict__ qkv, uint8_t* __restrict__ out_q,
+                                                           uint8_t* __restrict__ out_s, int S, int H, long ldq,
+                                                           long ldo, float scale_log2e) {
+  constexpr int SP = 32 * NKB;
+  constexpr int VP = SP + 4;  // bytes per V^T row: (SP + 4) / 4 odd -> the 32 rows of a b32 fragment read hit 32 banks
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sK = smem;                                   // [SP][64] e4m3, 8-byte chunk c of row r at c ^ ((r >> 2) & 7)
+  float* const sKs = reinterpret_cast<float*>(smem + SP * 64);   // [SP] scale of each key row
+  char* const sVt = smem + SP * 64 + SP * 4;               // [64][VP] e4m3
+  float* const red = reinterpret_cast<float*>(sVt + 64 * VP);    // [4]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int E = H * 64;
+  const int pair = blockIdx.x;
+  const int b = pair / H, h = pair - b * H;
+  const bf16* kbase = qkv + (long)b * S * ldq + E + h * 64;
+  const bf16* vbase = kbase + E;
+
+  // ---- stage K (quantised per row) and find V's absolute maximum ------------------------------------------------
+  uint4 vreg[NKB];
+  float vmax = 0.f;
+#pragma unroll
+  for (int it = 0; it < NKB; ++it) {
+    const int id = t + it * 256, row = id >> 3, c = id & 7;
+    const bool ok = row < S;
+    uint4 kv = make_uint4(0, 0, 0, 0);
+    vreg[it] = make_uint4(0, 0, 0, 0);
+    if (ok) {
+      kv = *reinterpret_cast<const uint4*>(kbase + (long)row * ldq + c * 8);
+      vreg[it] = *reinterpret_cast<const uint4*>(vbase + (long)row * ldq + c * 8);
+    }
+    const float kf[8] = {bf16_lo(kv.x), bf16_hi(kv.x), bf16_lo(kv.y), bf16_hi(kv.y),
+                         bf16_lo(kv.z), bf16_hi(kv.z), bf16_lo(kv.w), bf16_hi(kv.w)};
+    float am = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(kf[e]));
+    am = fmaxf(am, __shfl_xor(am, 1, 64));
+    am = fmaxf(am, __shfl_xor(am, 2, 64));
+    am = fmaxf(am, __shfl_xor(am, 4, 64));
+    const int sE = mx_scale_e8m0(am);
+    const float inv = mx_inv_scale(sE);
+    uint2 w;
+    w.x = mx_pack4(kf[0], kf[1], kf[2], kf[3], inv);
+    w.y = mx_pack4(kf[4], kf[5], kf[6], kf[7], inv);
+    *reinterpret_cast<uint2*>(sK + row * 64 + ((c ^ ((row >> 2) & 7)) << 3)) = w;
+    if (c == 0) sKs[row] = __uint_as_float((uint32_t)sE << 23);
+    const uint4 vv = vreg[it];
+    const float vf[8] = {bf16_lo(vv.x), bf16_hi(vv.x), bf16_lo(vv.y), bf16_hi(vv.y),
+                         bf16_lo(vv.z), bf16_hi(vv.z), bf16_lo(vv.w), bf16_hi(vv.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vmax = fmaxf(vmax, fabsf(vf[e]));
+  }
+  vmax = wave_max(vmax);
+  if (lane == 0) red[wave] = vmax;
+  __syncthreads();
+  vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const int sEv = mx_scale_e8m0(vmax);
+  const float inv_v = mx_inv_scale(sEv);
+  const float sv = __uint_as_float((uint32_t)sEv << 23);
+#pragma unroll
+  for (int it = 0; it < NKB; ++it) {
+    const int id = t + it * 256, row = id >> 3, c = id & 7;
+    const uint4 vv = vreg[it];
+    const uint32_t w0 = mx_pack4(bf16_lo(vv.x), bf16_hi(vv.x), bf16_lo(vv.y), bf16_hi(vv.y), inv_v);
+    const uint32_t w1 = mx_pack4(bf16_lo(vv.z), bf16_hi(vv.z), bf16_lo(vv.w), bf16_hi(vv.w), inv_v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sVt[(c * 8 + e) * VP + row] = (char)((w0 >> (8 * e)) & 0xff);
+      sVt[(c * 8 + 4 + e) * VP + row] = (char)((w1 >> (8 * e)) & 0xff);
+    }
+  }
+  __syncthreads();
+
+  const int r32 = lane & 31, h2 = lane >> 5;
+  for (int qb = wave; qb < NKB; qb += 4) {  // wave-uniform
+    if (qb * 32 >= S) continue;
+    const int query = qb * 32 + r32;
+    const bool q_ok = query < S;
+    const bf16* qrow = qkv + ((long)b * S + (q_ok ? query : 0)) * ldq + h * 64;
+    float qv[4][8];
+    float qam = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (q_ok) u = *reinterpret_cast<const uint4*>(qrow + ks * 16 + h2 * 8);
+      qv[ks][0] = bf16_lo(u.x); qv[ks][1] = bf16_hi(u.x); qv[ks][2] = bf16_lo(u.y); qv[ks][3] = bf16_hi(u.y);
+      qv[ks][4] = bf16_lo(u.z); qv[ks][5] = bf16_hi(u.z); qv[ks][6] = bf16_lo(u.w); qv[ks][7] = bf16_hi(u.w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qam = fmaxf(qam, fabsf(qv[ks][e]));
+    }
+    qam = fmaxf(qam, __shfl_xor(qam, 32, 64));
+    const int sEq = mx_scale_e8m0(qam);
+    const float inv_q = mx_inv_scale(sEq);
+    const float sq = __uint_as_float((uint32_t)sEq << 23);
+    long qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint32_t lo = mx_pack4(qv[ks][0], qv[ks][1], qv[ks][2], qv[ks][3], inv_q);
+      const uint32_t hi = mx_pack4(qv[ks][4], qv[ks][5], qv[ks][6], qv[ks][7], inv_q);
+      qf[ks] = (long)(((unsigned long)hi << 32) | lo);
+    }
+
+    f32x16 sc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
+      const int krow = kb * 32 + r32;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const long kf = *reinterpret_cast<const long*>(sK + krow * 64 + (((ks * 2 + h2) ^ ((krow >> 2) & 7)) << 3));
+        sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf, qf[ks], sc[kb], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 sk4 = *reinterpret_cast<const float4*>(sKs + kb * 32 + 8 * g + 4 * h2);
+        const float skv[4] = {sk4.x, sk4.y, sk4.z, sk4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float v = sc[kb][r] * (sq * skv[e]);
+          if (kb == NKB - 1 && kb * 32 + 8 * g + 4 * h2 + e >= S) v = -INFINITY;
+          sc[kb][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pe = __builtin_amdgcn_exp2f((sc[kb][r] - mx) * scale_log2e);
+        sc[kb][r] = pe;
+        sum += pe;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+
+    f32x16 o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint32_t plo = mx_pack4(sc[kb][8 * s + 0], sc[kb][8 * s + 1], sc[kb][8 * s + 2], sc[kb][8 * s + 3], 256.f);
+        const uint32_t phi = mx_pack4(sc[kb][8 * s + 4], sc[kb][8 * s + 5], sc[kb][8 * s + 6], sc[kb][8 * s + 7], 256.f);
+        const long pb = (long)(((unsigned long)phi << 32) | plo);
+        const int key0 = kb * 32 + 16 * s + 4 * h2;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const char* vrow = sVt + (db * 32 + r32) * VP + key0;
+          const uint32_t lo = *reinterpret_cast<const uint32_t*>(vrow);
+          const uint32_t hi = *reinterpret_cast<const uint32_t*>(vrow + 8);
+          const long vf = (long)(((unsigned long)hi << 32) | lo);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pb, o[db], 0, 0, 0);
+        }
+      }
+    }
+    const float fin = sv * (1.0f / 256.0f) / sum;
+    const long token = (long)b * S + query;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      float am = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[db][r] = (float)(bf16)(o[db][r] * fin);   // the bf16 storage point of the per-op path
+        am = fmaxf(am, fabsf(o[db][r]));
+      }
+      am = fmaxf(am, __shfl_xor(am, 32, 64));
+      const int sE = mx_scale_e8m0(am);
+      const float inv = mx_inv_scale(sE);
+      if (q_ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<uint32_t*>(out_q + token * ldo + h * 64 + db * 32 + 8 * g + 4 * h2) =
+              mx_pack4(o[db][4 * g + 0], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3], inv);
+        if (h2 == 0) out_s[mx_scale_offset(token, h * 64 + db * 32, E)] = (uint8_t)sE;
+      }
+    }
+  }
+}
+
+template <int NKB>
+int launch_attn_fwd_fp8(const bf16* qkv, uint8_t* out_q, uint8_t* out_s, int B, int S, int H, long ldq, long ldo,
+                        float scale, hipStream_t st) {
+  constexpr int SP = 32 * NKB;
+  constexpr int LDS = SP * 64 + SP * 4 + 64 * (SP + 4) + 16;
+  hipLaunchKernelGGL((attn_fwd_fp8_kernel<NKB>), dim3((unsigned)(B * H)), dim3(256), LDS, st, qkv, out_q, out_s, S, H, ldq,
+                     ldo, scale * 1.44269504088896340736f);
+  RVIT_CHECK_LAUNCH("attn_fwd_fp8");
+  return RVIT_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Backward (autograd of scaled_dot_product_attention, run by train_vit.py:939).  P is recomputed
@@ -509,5 +723,29 @@ int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const flo
     case 8: return launch_attn_bwd<8>(q, o, d, lse, dq, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
   }
   rvit_set_error("attn_bwd: S=%d unsupported", S);
+  return RVIT_EUNSUPPORTED;
+}
+
+int rvit_attn_fwd_fp8_impl(const void* qkv, uint8_t* out_q, long ldo, uint8_t* out_s, int B, int S, int H, long ldq,
+                           float scale, hipStream_t st) {
+  RVIT_CHECK_ARG(qkv && out_q && out_s, "attn_fwd_fp8: null pointer");
+  RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_fwd_fp8: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
+  RVIT_CHECK_ARG((H & 1) == 0, "attn_fwd_fp8: H * 64 must be a multiple of 128 (MX operand of the out_proj), H=%d", H);
+  RVIT_CHECK_ARG(ldq >= 3L * H * 64 && (ldq & 7) == 0 && ldo >= (long)H * 64 && (ldo & 3) == 0,
+                 "attn_fwd_fp8: bad pitches ldq=%ld ldo=%ld", ldq, ldo);
+  RVIT_CHECK_ARG(rvit_aligned16(qkv) && ((uintptr_t)out_q & 3) == 0, "attn_fwd_fp8: alignment");
+  RVIT_CHECK_ARG((long)B * H < 0x7fffffffL, "attn_fwd_fp8: too many (image, head) pairs");
+  const bf16* q = (const bf16*)qkv;
+  switch ((S + 31) / 32) {
+    case 1: return launch_attn_fwd_fp8<1>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 2: return launch_attn_fwd_fp8<2>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 3: return launch_attn_fwd_fp8<3>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 4: return launch_attn_fwd_fp8<4>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 5: return launch_attn_fwd_fp8<5>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 6: return launch_attn_fwd_fp8<6>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 7: return launch_attn_fwd_fp8<7>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 8: return launch_attn_fwd_fp8<8>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+  }
+  rvit_set_error("attn_fwd_fp8: S=%d unsupported", S);
   return RVIT_EUNSUPPORTED;
 }

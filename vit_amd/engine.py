@@ -215,8 +215,8 @@ class Engine:
             # LayerNorm emits its result directly as MX-fp8 (same bytes as layernorm -> quantize_mx, one pass)
             ops.layernorm_mx(x2, L["ln1_w"], L["ln1_b"], aq, as_, L["eps1"])
             ops.gemm_mx(aq, as_, L["qkv_w_q"], L["qkv_w_s"], b["qkv"], bias=L["qkv_b"])
-            ops.attention(b["qkv"], b["att"], B, S, H)
-            ops.quantize_mx(b["att"], aq, as_)
+            # both attention products on the fp8 MFMA; the result is written as the MX operand of the out_proj
+            ops.attention_fp8(b["qkv"], aq, as_, B, S, H)
             ops.gemm_mx(aq, as_, L["out_w_q"], L["out_w_s"], x2, bias=L["out_b"], residual=x2)
             ops.layernorm_mx(x2, L["ln2_w"], L["ln2_b"], aq, as_, L["eps2"])
             # linear1's epilogue emits the GELU output directly as MX-fp8 (no bf16 copy, no quantisation pass)

@@ -515,6 +515,25 @@ def encoder_mlp_supported(E: int, hidden: int) -> bool:
     return E == 256 and hidden > 0 and hidden % 256 == 0
 
 
+def attention_fp8(qkv: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, B: int, S: int, H: int,
+                  scale: Optional[float] = None):
+    """fp8-MFMA attention with MXFP8 output: qkv bf16 [B*S, 3*H*64]; out_q uint8 [B*S, H*64] (e4m3), out_s the tiled
+    E8M0 scales (ops.mx_scale_shape(B*S, H*64)): the A operand of the out_proj's gemm_mx."""
+    _need_cuda(qkv, out_q, out_s)
+    T, W3, ldq = _rows2d(qkv, "attention_fp8 qkv")
+    E = H * 64
+    if T != B * S or W3 != 3 * E or qkv.dtype != BF16 or E % 128:
+        raise ValueError(f"attention_fp8: qkv {tuple(qkv.shape)} does not match B={B} S={S} H={H} (H even)")
+    if tuple(out_q.shape) != (T, E) or out_q.dtype != torch.uint8 or out_q.stride(1) != 1 \
+            or tuple(out_s.shape) != mx_scale_shape(T, E) or out_s.dtype != torch.uint8 or not out_s.is_contiguous():
+        raise ValueError("attention_fp8: out_q [T,E] / tiled out_s (ops.mx_scale_shape) must be uint8")
+    sc = (1.0 / 8.0) if scale is None else float(scale)
+    with _Span("attn_fwd_fp8", 4 * B * H * S * S * 64, qkv.numel() * 2 + out_q.numel()):
+        check(_lib.load().rvit_attn_fwd_fp8(qkv.data_ptr(), out_q.data_ptr(), out_q.stride(0), out_s.data_ptr(), B, S, H,
+                                            ldq, sc, _stream()), "rvit_attn_fwd_fp8")
+    return out_q, out_s
+
+
 # =================================================================================================
 # backward / loss kernels
 # =================================================================================================
