@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 13
+#define RVIT_ABI_VERSION 14
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -140,26 +140,38 @@ int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, i
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* bias,
                            const float* pos_embed, float drop_p, uint64_t drop_seed, int tile, void* stream);
 
-/* Weight gradient of a Linear: dW[N_store,K] += dY[M,N]^T . X[M,K] (fp32 atomics, accumulates like
- * autograd's .grad).  dY: bf16 [.,ldy], X: bf16 [.,ldx], optional row remaps; N, K, ldy, ldx
+/* Ordered (bit-reproducible) reductions.  The reference asks its backend for deterministic kernels
+ * (train_vit.py:50).  The entry points below that take `workspace` / `workspace_bytes` end a reduction that is split
+ * over workgroups either with fp32 atomics (workspace == NULL: arrival order, last bits differ from run to run) or,
+ * given a caller-owned device workspace, by storing one partial per split and adding the partials in ascending split
+ * order in a second kernel: same bits on every run.  The workspace is scratch (no state survives the call), 16-byte
+ * aligned; calls that share it must be ordered on one stream.  Weight gradients size their split count to what it
+ * holds (one split needs N_store * K * 4 bytes, two for the variants where two wave groups share a tile); the
+ * column-sum entries need at most 4 MiB.  RVIT_ORDERED_WORKSPACE_BYTES serves every layer of the models built here. */
+#define RVIT_ORDERED_WORKSPACE_BYTES (192u << 20)
+
+/* Weight gradient of a Linear: dW[N_store,K] += dY[M,N]^T . X[M,K] (accumulates like autograd's .grad; fp32 atomics,
+ * or ordered with a workspace).  dY: bf16 [.,ldy], X: bf16 [.,ldx], optional row remaps; N, K, ldy, ldx
  * multiples of 8; rows n >= N_store of the product are discarded (padded logits).
  * splits: number of M partitions (0 = automatic; -3 / -4 force / forbid the sixteen-wave 256x256-tile variant that
  * long plain products run, for tests). */
 int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extra, const void* X, int64_t ldx,
                     int x_row_group, int x_row_extra, float* dW, int64_t ldw, int64_t M, int N, int N_store, int K,
-                    int splits, void* stream);
+                    int splits, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Weight AND bias gradient of a Linear in one launch: dW[N_store,K] += dY^T . X as rvit_wgrad_bf16 (no row remaps) and
  * dbias[N_store] += column sums of dY (autograd of the encoder's nn.Linear layers, train_vit.py:141-171, run by
  * train_vit.py:939).  For N > 64 the sums ride the matrix pipe of the workgroups that own the first K tile (one extra
  * MFMA per four); for N <= 64 (the classifier head) it is the weight-gradient kernel followed by rvit_colsum_bf16. */
 int rvit_linear_wgrad_bias_bf16(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw,
-                                float* dbias, int64_t M, int N, int N_store, int K, int splits, void* stream);
+                                float* dbias, int64_t M, int N, int N_store, int K, int splits, void* workspace,
+                                int64_t workspace_bytes, void* stream);
 
 /* Weight gradient of the NHWC convolution: dW[Cout, KH*KW*seg_len] += dy^T . gather(x), same
  * geometry arguments and weight layout as rvit_conv2d_fwd_bf16. */
 int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int H, int W, int Cpix, int seg_len,
-                           int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, int splits, void* stream);
+                           int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, int splits, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 
 /* Fused stem entry for inference: conv 7x7/2 pad 3 (3->64) + folded BatchNorm (scale, bias) + ReLU +
  * max-pool 3x3/2 pad 1 in one kernel; the 112x112x64 map never reaches HBM.  Replaces timm resnet
@@ -239,10 +251,11 @@ int rvit_encoder_attn_fwd(float* x, const float* gamma, const float* beta, float
  * (x + f(LN(x)), torch transformer.py:947-950):  dx (+)= LN'(dy); dgamma += ..., dbeta += ...
  *   dy: bf16 [rows,lddy]; x: f32 [rows,ldx] (the LN input); mean/rstd from the forward;
  *   dx: f32 [rows,lddx], accumulate != 0 adds to its content; dx_bf16: optional bf16 copy of the
- *   updated dx; dgamma/dbeta: f32 [E], accumulated with atomics. */
+ *   updated dx; dgamma/dbeta: f32 [E], accumulated (atomics, or ordered with a workspace). */
 int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
-                       void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* stream);
+                       void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 
 /* softmax(q k^T * scale) v per (batch, head), head_dim 64, S <= 256, no mask
  * (torch functional.py:6623-6631 -> scaled_dot_product_attention).
@@ -277,9 +290,9 @@ int rvit_ce_loss(const float* logits, int64_t ldl, const int64_t* labels, float*
                  int64_t lddl, void* dlogits_bf16, int64_t lddb, int B, int C, int C_pad, float label_smoothing,
                  float grad_scale, void* stream);
 
-/* out[n] += sum_m a[m,n]  (bias gradients); a bf16 [.,lda] with optional row remap. */
+/* out[n] += sum_m a[m,n]  (bias gradients); a bf16 [.,lda] with optional row remap; ordered with a workspace. */
 int rvit_colsum_bf16(const void* a, int64_t lda, float* out, int64_t M, int N, int64_t row_group, int64_t row_extra,
-                     void* stream);
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[j] += sum_b x[b*ldb + j], j < n  (pos_embed / cls_token gradients: token gradients summed
  * over the batch; backward of the broadcast add at train_vit.py:155-159). */
@@ -330,8 +343,8 @@ int rvit_maxpool3x3s2_bwd_nhwc(const void* dpool, const void* argmax, void* dx, 
                                void* stream);
 
 /* *out += sum_i x[i]^2 (fp32; the caller zeroes *out).  Squared global gradient norm for
- * torch.nn.utils.clip_grad_norm_ (train_vit.py:942-943) over the flat gradient buffer. */
-int rvit_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+ * torch.nn.utils.clip_grad_norm_ (train_vit.py:942-943) over the flat gradient buffer; ordered with a workspace. */
+int rvit_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* One AdamW step over flat fp32 buffers, torch.optim.AdamW semantics (train_vit.py:879-883,945: decoupled
  * weight decay, bias correction with `step` >= 1), fused with gradient clipping: when grad_norm_sq is not

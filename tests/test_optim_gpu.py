@@ -27,7 +27,7 @@ def test_kernels_against_torch_adamw(dev):
         want_norm = torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
         opt.step()
         nsq.zero_()
-        check(lib.rvit_sumsq_f32(g.data_ptr(), n, nsq.data_ptr(), _stream()), "sumsq")
+        check(lib.rvit_sumsq_f32(g.data_ptr(), n, nsq.data_ptr(), None, 0, _stream()), "sumsq")
         check(lib.rvit_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 3e-3, 0.9, 0.95, 1e-8,
                                   0.05, step, nsq.data_ptr(), 1.0, mirror.data_ptr() if step > 1 else None,
                                   _stream()), "adamw")

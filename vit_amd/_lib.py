@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -42,9 +42,9 @@ SIGNATURES = {
     "rvit_conv2d_dgrad_s2_bf16": ([P, P, P, I, I, I, I, I, P, P], c_int),
     "rvit_conv1x1_dgrad_s2_acc_bf16": ([P, P, P, I, I, I, I, I, P], c_int),
     "rvit_conv2d_tokens_fwd": ([P, P, P] + [I] * 12 + [P, P, F, U64, I, P], c_int),
-    "rvit_wgrad_bf16": ([P, L, I, I, P, L, I, I, P, L, L, I, I, I, I, P], c_int),
-    "rvit_linear_wgrad_bias_bf16": ([P, L, P, L, P, L, P, L, I, I, I, I, P], c_int),
-    "rvit_conv2d_wgrad_bf16": ([P, P, P] + [I] * 12 + [I, P], c_int),
+    "rvit_wgrad_bf16": ([P, L, I, I, P, L, I, I, P, L, L, I, I, I, I, P, L, P], c_int),
+    "rvit_linear_wgrad_bias_bf16": ([P, L, P, L, P, L, P, L, I, I, I, I, P, L, P], c_int),
+    "rvit_conv2d_wgrad_bf16": ([P, P, P] + [I] * 12 + [I, P, L, P], c_int),
     "rvit_stem_conv1_pool_fwd": ([P, P, P, P, P, I, I, P], c_int),
     "rvit_stem_conv1_pool_f32_fwd": ([P, P, P, P, P, I, I, P], c_int),
     "rvit_input_pack_nhwc4": ([P, P] + [I] * 8 + [P], c_int),
@@ -56,14 +56,14 @@ SIGNATURES = {
     "rvit_layernorm_fwd": ([P, I, L, P, P, P, I, L, P, P, L, I, F, P], c_int),
     "rvit_encoder_mlp_fwd": ([P, P, P, F, P, P, P, P, L, I, I, I, P], c_int),
     "rvit_encoder_attn_fwd": ([P, P, P, F, P, P, P, P, I, I, I, I, P], c_int),
-    "rvit_layernorm_bwd": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P], c_int),
+    "rvit_layernorm_bwd": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P, L, P], c_int),
     "rvit_attn_fwd": ([P, P, P, I, I, I, L, L, F, F, U64, P], c_int),
     "rvit_attn_fwd_fp8": ([P, P, L, P, I, I, I, L, F, P], c_int),
     "rvit_attn_bwd": ([P, P, P, P, P, I, I, I, L, L, L, L, F, F, U64, P], c_int),
     "rvit_ce_loss": ([P, L, P, P, P, L, P, L, I, I, I, F, F, P], c_int),
-    "rvit_colsum_bf16": ([P, L, P, L, I, L, L, P], c_int),
+    "rvit_colsum_bf16": ([P, L, P, L, I, L, L, P, L, P], c_int),
     "rvit_batch_sum_f32": ([P, L, P, I, L, P], c_int),
-    "rvit_sumsq_f32": ([P, L, P, P], c_int),
+    "rvit_sumsq_f32": ([P, L, P, P, L, P], c_int),
     "rvit_adamw_step": ([P, P, P, P, L, F, F, F, F, F, I, P, F, P, P], c_int),
     "rvit_cast_bf16": ([P, P, L, P], c_int),
     "rvit_lstm_step_fwd": ([P] * 13 + [I] * 5 + [P], c_int),

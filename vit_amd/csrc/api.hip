@@ -204,8 +204,9 @@ int rvit_conv2d_tokens_fwd(const void* x, const void* w, float* tokens, int B, i
 
 int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extra, const void* X, int64_t ldx,
                     int x_row_group, int x_row_extra, float* dW, int64_t ldw, int64_t M, int N, int N_store, int K,
-                    int splits, void* stream) {
+                    int splits, void* workspace, int64_t workspace_bytes, void* stream) {
   WgradArgs a{};
+  a.ws = (float*)workspace; a.ws_bytes = workspace ? (size_t)workspace_bytes : 0;
   a.dY = (const bf16*)dY; a.ldy = ldy; a.y_row_group = y_row_group; a.y_row_extra = y_row_extra;
   a.X = (const bf16*)X; a.ldx = ldx; a.x_row_group = x_row_group; a.x_row_extra = x_row_extra;
   a.dW = dW; a.ldw = ldw; a.M = M; a.N = N; a.N_store = N_store; a.K = K; a.mode = 0; a.splits = splits;
@@ -213,9 +214,11 @@ int rvit_wgrad_bf16(const void* dY, int64_t ldy, int y_row_group, int y_row_extr
 }
 
 int rvit_linear_wgrad_bias_bf16(const void* dY, int64_t ldy, const void* X, int64_t ldx, float* dW, int64_t ldw,
-                                float* dbias, int64_t M, int N, int N_store, int K, int splits, void* stream) {
+                                float* dbias, int64_t M, int N, int N_store, int K, int splits, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
   RVIT_CHECK_ARG(dbias, "linear_wgrad_bias: null dbias");
   WgradArgs a{};
+  a.ws = (float*)workspace; a.ws_bytes = workspace ? (size_t)workspace_bytes : 0;
   a.dY = (const bf16*)dY; a.ldy = ldy;
   a.X = (const bf16*)X; a.ldx = ldx;
   a.dW = dW; a.ldw = ldw; a.M = M; a.N = N; a.N_store = N_store; a.K = K; a.mode = 0; a.splits = splits;
@@ -226,12 +229,12 @@ int rvit_linear_wgrad_bias_bf16(const void* dY, int64_t ldy, const void* X, int6
   // narrow outputs (the classifier head): the four-wave narrow kernel has no spare wave for the sums
   const int rc = rvit_wgrad_dispatch(a, (hipStream_t)stream);
   if (rc != RVIT_OK) return rc;
-  return rvit_colsum_impl(dY, ldy, dbias, M, N_store, 0, 0, (hipStream_t)stream);
+  return rvit_colsum_impl(dY, ldy, dbias, M, N_store, 0, 0, a.ws, a.ws_bytes, (hipStream_t)stream);
 }
 
 int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, int splits,
-                           void* stream) {
+                           void* workspace, int64_t workspace_bytes, void* stream) {
   RVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
                  "conv wgrad: bad geometry");
   RVIT_CHECK_ARG((long)B * H * W < 0x7fffffffL && (long)B * Ho * Wo < 0x7fffffffL, "conv wgrad: too many pixels");
@@ -243,6 +246,7 @@ int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int 
   a.mode = 1;
   a.H = H; a.W = W; a.Cpix = Cpix; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
   a.seg_len = seg_len; a.splits = splits;
+  a.ws = (float*)workspace; a.ws_bytes = workspace ? (size_t)workspace_bytes : 0;
   return rvit_wgrad_dispatch(a, (hipStream_t)stream);
 }
 
@@ -313,9 +317,11 @@ int rvit_attn_fwd_fp8(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out
 
 int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
-                       void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* stream) {
+                       void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
   return rvit_layernorm_bwd_impl(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, accumulate, dx_bf16, lddb, dgamma,
-                                 dbeta, rows, E, (hipStream_t)stream);
+                                 dbeta, rows, E, (float*)workspace, workspace ? (size_t)workspace_bytes : 0,
+                                 (hipStream_t)stream);
 }
 
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
@@ -338,16 +344,17 @@ int rvit_ce_loss(const float* logits, int64_t ldl, const int64_t* labels, float*
 }
 
 int rvit_colsum_bf16(const void* a, int64_t lda, float* out, int64_t M, int N, int64_t row_group, int64_t row_extra,
-                     void* stream) {
-  return rvit_colsum_impl(a, lda, out, M, N, row_group, row_extra, (hipStream_t)stream);
+                     void* workspace, int64_t workspace_bytes, void* stream) {
+  return rvit_colsum_impl(a, lda, out, M, N, row_group, row_extra, (float*)workspace,
+                          workspace ? (size_t)workspace_bytes : 0, (hipStream_t)stream);
 }
 
 int rvit_batch_sum_f32(const float* x, int64_t ldb, float* out, int B, int64_t n, void* stream) {
   return rvit_batch_sum_impl(x, ldb, out, B, n, (hipStream_t)stream);
 }
 
-int rvit_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
-  return rvit_sumsq_impl(x, n, out, (hipStream_t)stream);
+int rvit_sumsq_f32(const float* x, int64_t n, float* out, void* workspace, int64_t workspace_bytes, void* stream) {
+  return rvit_sumsq_impl(x, n, out, (float*)workspace, workspace ? (size_t)workspace_bytes : 0, (hipStream_t)stream);
 }
 
 int rvit_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

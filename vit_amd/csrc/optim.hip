@@ -10,7 +10,8 @@ namespace {
 
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return (unsigned short)(pack_bf16x2(x, 0.f) & 0xffffu); }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out,
+                                                    float* __restrict__ ws) {
   __shared__ float red[4];
   const long n4 = n >> 2;
   float s = 0.f;
@@ -25,7 +26,11 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const float t = ((red[0] + red[1]) + red[2]) + red[3];
+    if (ws) ws[blockIdx.x * 4] = t;   // ordered mode: one slot per workgroup, added in order by rvit_ordered_finalize
+    else atomicAdd(out, t);
+  }
 }
 
 // torch.optim.AdamW semantics (decoupled weight decay, bias correction, eps outside the bias-corrected sqrt):
@@ -152,14 +157,16 @@ int rvit_transpose_batched_impl(const bf16* src, bf16* dst, const long* table, i
   return RVIT_OK;
 }
 
-int rvit_sumsq_impl(const float* x, long n, float* out, hipStream_t st) {
+int rvit_sumsq_impl(const float* x, long n, float* out, float* ws, size_t ws_bytes, hipStream_t st) {
   RVIT_CHECK_ARG(x && out && n >= 0 && rvit_aligned16(x), "sumsq: bad arguments");
   if (n == 0) return RVIT_OK;
   long blocks = (n / 4 + 255) / 256;
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out);
+  if (ws) RVIT_CHECK_ARG(ws_bytes >= (size_t)blocks * 16, "sumsq: the ordered-reduction workspace needs %zu bytes", (size_t)blocks * 16);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, out, ws);
   RVIT_CHECK_LAUNCH("sumsq");
+  if (ws) return rvit_ordered_finalize(ws, (int)blocks, 4, out, 1, 1, 1, st);
   return RVIT_OK;
 }
 

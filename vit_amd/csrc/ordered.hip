@@ -1,0 +1,120 @@
+// Ordered (bit-reproducible) completion of split reductions.  The reference asks its backend for deterministic
+// kernels (train_vit.py:50, torch.backends.cudnn.deterministic = True).  Every reduction of the training path that is
+// split over workgroups - weight gradients (split over the M range), bias / LayerNorm-affine column sums, the
+// gradient norm - normally ends in fp32 atomics, whose arrival order differs from run to run.  With a caller-owned
+// workspace the producers instead STORE one partial result per split ("slot") and this kernel adds the slots in
+// ascending order:
+//   out[r * ld + c] += sum_{s = 0 .. nslots-1} part[s * slot_stride + r * cols + c]
+// HBM-bound: nslots * rows * cols * 4 bytes read, one read-modify-write of out.
+#include "common.h"
+#include "rvit_internal.h"
+
+namespace {
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void ordered_finalize_kernel(const float* __restrict__ part, int nslots, long slot_stride,
+                                                               float* __restrict__ out, long rows, int cols, long ld) {
+  constexpr int W = VEC4 ? 4 : 1;
+  const long per_row = cols / W;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * per_row) return;
+  const long r = i / per_row;
+  const int c = (int)(i - r * per_row) * W;
+  const float* src = part + r * cols + c;
+  float* dst = out + r * ld + c;
+  if constexpr (VEC4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= nslots; s += 4) {   // four loads in flight; the additions stay in slot order
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)(s + j) * slot_stride));
+        v[j] = make_float4(u[0], u[1], u[2], u[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { t.x += v[j].x; t.y += v[j].y; t.z += v[j].z; t.w += v[j].w; }
+    }
+    for (; s < nslots; ++s) {
+      const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)s * slot_stride));
+      const float4 v = make_float4(u[0], u[1], u[2], u[3]);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float4 o = *reinterpret_cast<float4*>(dst);
+    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+    *reinterpret_cast<float4*>(dst) = o;
+  } else {
+    float t = 0.f;
+    for (int s = 0; s < nslots; ++s) t += src[(long)s * slot_stride];
+    *dst += t;
+  }
+}
+
+// Few outputs, many slots (the gradient norm: one output, 512 slots; LayerNorm affine gradients: 256-1024 outputs,
+// 256 slots): G lanes per output, lane g adds slots g, g + G, ... in order, then the fixed xor butterfly over the G
+// lanes: still one association on every run, without a slots-deep dependent chain in one thread.
+template <int G>
+__global__ __launch_bounds__(256) void ordered_finalize_wide_kernel(const float* __restrict__ part, int nslots, long slot_stride,
+                                                                    float* __restrict__ out, long n_out, int cols, long ld) {
+  const long o = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+  const int g = threadIdx.x % G;
+  const bool ok = o < n_out;
+  const long r = ok ? o / cols : 0;
+  const int c = ok ? (int)(o - r * cols) : 0;
+  const float* src = part + r * cols + c;
+  float t = 0.f;
+  if (ok)
+    for (int s = g; s < nslots; s += G) t += src[(long)s * slot_stride];
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if (ok && g == 0) out[r * ld + c] += t;
+}
+
+}  // namespace
+
+int rvit_ordered_finalize(const float* part, int nslots, long slot_stride, float* out, long rows, int cols, long ld,
+                          hipStream_t st) {
+  RVIT_CHECK_ARG(part && out && nslots > 0 && rows > 0 && cols > 0 && ld >= cols, "ordered_finalize: bad arguments");
+  const long n_out = rows * cols;
+  if (n_out <= 16 && nslots >= 64) {
+    hipLaunchKernelGGL(ordered_finalize_wide_kernel<64>, dim3((unsigned)((n_out * 64 + 255) / 256)), dim3(256), 0, st, part, nslots,
+                       slot_stride, out, n_out, cols, ld);
+    RVIT_CHECK_LAUNCH("ordered_finalize");
+    return RVIT_OK;
+  }
+  if (n_out <= 16384 && nslots >= 32) {
+    hipLaunchKernelGGL(ordered_finalize_wide_kernel<16>, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, st, part, nslots,
+                       slot_stride, out, n_out, cols, ld);
+    RVIT_CHECK_LAUNCH("ordered_finalize");
+    return RVIT_OK;
+  }
+  const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && (slot_stride & 3) == 0 && rvit_aligned16(part) && rvit_aligned16(out);
+  const long n = rows * (vec ? cols / 4 : cols);
+  RVIT_CHECK_ARG((n + 255) / 256 < 0x7fffffffL, "ordered_finalize: too many elements");
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (vec) hipLaunchKernelGGL(ordered_finalize_kernel<true>, grid, dim3(256), 0, st, part, nslots, slot_stride, out, rows, cols, ld);
+  else hipLaunchKernelGGL(ordered_finalize_kernel<false>, grid, dim3(256), 0, st, part, nslots, slot_stride, out, rows, cols, ld);
+  RVIT_CHECK_LAUNCH("ordered_finalize");
+  return RVIT_OK;
+}
+
+// Split count of an ordered reduction over `units` work items: at most what the workspace holds (`sub` slots of
+// `elems` floats per split), and such that no split is empty (every slot the finalisation reads has been written).
+int rvit_ordered_splits(long units, long splits, int sub, long elems, size_t ws_bytes, const char* what, long* out) {
+  const long cap = (long)(ws_bytes / 4 / (size_t)(sub * elems > 0 ? sub * elems : 1));
+  if (cap < 1) {
+    rvit_set_error("%s: the ordered-reduction workspace holds %zu bytes, one split needs %ld", what, ws_bytes, sub * elems * 4);
+    return RVIT_EINVAL;
+  }
+  if (splits > cap) splits = cap;
+  if (splits > units) splits = units;
+  if (splits < 1) splits = 1;
+  for (;;) {
+    const long per = (units + splits - 1) / splits;
+    const long need = (units + per - 1) / per;
+    if (need == splits) break;
+    splits = need;
+  }
+  *out = splits;
+  return RVIT_OK;
+}

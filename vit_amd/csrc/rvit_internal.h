@@ -71,7 +71,7 @@ struct MxGemmArgs {
   long ldcq;
   uint8_t* SCq;       // ... with its E8M0 scales, tiled [ceil(M/16)][ceil(N/512)][16][4][4]
 };
-int rvit_sumsq_impl(const float* x, long n, float* out, hipStream_t st);  // optim.hip
+int rvit_sumsq_impl(const float* x, long n, float* out, float* ws, size_t ws_bytes, hipStream_t st);  // optim.hip
 int rvit_adamw_impl(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                     float wd, int step, const float* gnorm_sq, float max_norm, bf16* mirror, hipStream_t st);
 int rvit_preprocess_impl(const uint8_t* img, int B, int H, int W, int C, const int* hcoef, const int* hbounds, int hk,
@@ -113,7 +113,20 @@ struct WgradArgs {
   int H, W, Cpix, Ho, Wo, KW, stride, pad, seg_len;
   float* dbias;    // optional [N_store] fp32: += column sums of dY (plain mode, N > 64; the dispatcher checks)
   int splits;      // 0 = auto; > 0 M splits of the implicit-GEMM kernel; -1 force that kernel; -2 force the direct 3x3 kernel
+  // ordered mode (ordered.hip): host side, the caller's workspace ...
+  float* ws;       // null: fp32 atomics into dW / dbias
+  size_t ws_bytes;
+  // ... device side, filled by the dispatcher: split s (sub-slot u of `sub`) stores its tile at
+  // part + (s * sub + u) * part_stride + n * K + k and its bias sums at part_bias + (s * sub + u) * N_store + n
+  float* part;
+  long part_stride;
+  float* part_bias;
+  int part_sub;    // slots per split (2 where two wave groups share an output tile)
 };
+
+int rvit_ordered_finalize(const float* part, int nslots, long slot_stride, float* out, long rows, int cols, long ld,
+                          hipStream_t st);
+int rvit_ordered_splits(long units, long splits, int sub, long elems, size_t ws_bytes, const char* what, long* out);
 
 int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st);
 bool rvit_conv3x3_wgrad_direct_ok(const WgradArgs& a);            // wgrad3x3.hip
@@ -126,7 +139,8 @@ int rvit_layernorm_mx_fwd_impl(const void* x, int x_f32, long ldx, const float* 
                                long ldq, uint8_t* sc, long rows, int E, float eps, hipStream_t st);
 int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                             const float* gamma, float* dxs, long lddx, int accumulate, void* dx_bf16, long lddb,
-                            float* dgamma, float* dbeta, long rows, int E, hipStream_t st);
+                            float* dgamma, float* dbeta, long rows, int E, float* ws, size_t ws_bytes,
+                            hipStream_t st);
 int rvit_encoder_mlp_impl(float* x, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
                           const void* w2, const float* b2, long T, int E, int hidden, int rows_per_wg, hipStream_t st);
 int rvit_encoder_attn_impl(float* x, const float* gamma, const float* beta, float eps, const void* wqkv,
@@ -150,7 +164,7 @@ int rvit_embed_cls_impl(const float* cls, const float* pos, float* x, int B, int
 int rvit_ce_loss_impl(const float* logits, long ldl, const long* labels, float* loss_sum, float* dlogits, long lddl,
                       void* dlogits_bf16, long lddb, int B, int C, int C_pad, float eps, float gscale, hipStream_t st);
 int rvit_colsum_impl(const void* a, long lda, float* out, long M, int N, long row_group, long row_extra,
-                     hipStream_t st);
+                     float* ws, size_t ws_bytes, hipStream_t st);
 int rvit_batch_sum_impl(const float* x, long ldb, float* out, int B, long n, hipStream_t st);
 int rvit_bn_stats_impl(const void* y, long M, int C, float* sums, float* ws, hipStream_t st);
 int rvit_bn_apply_impl(const void* y, const float* sums, const float* gamma, const float* beta, const void* res,

@@ -22,14 +22,17 @@ __global__ __launch_bounds__(THREADS) void layernorm_bwd_kernel(const bf16* __re
                                                             const float* __restrict__ gamma, float* __restrict__ dxs,
                                                             long lddx, int accumulate, bf16* __restrict__ dx_bf16,
                                                             long lddb, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, long rows, int E) {
-  extern __shared__ float lnb_red[];  // [2 * IT * 256]
+                                                            float* __restrict__ dbeta, long rows, int E,
+                                                            float* __restrict__ ws) {
+  extern __shared__ float lnb_red[];  // [2 * IT * 256]; ordered mode (ws): one such vector per wave
   constexpr int WAVES = THREADS / 64;
   const int lane = threadIdx.x & 63;
   const long wave_id = (long)blockIdx.x * WAVES + (threadIdx.x >> 6);
   const long nwaves = (long)gridDim.x * WAVES;
-  for (int i = threadIdx.x; i < 2 * IT * 256; i += THREADS) lnb_red[i] = 0.f;
-  __syncthreads();
+  if (!ws) {
+    for (int i = threadIdx.x; i < 2 * IT * 256; i += THREADS) lnb_red[i] = 0.f;
+    __syncthreads();
+  }
   float gam[IT][4], dg[IT][4], db[IT][4];
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
@@ -90,6 +93,25 @@ __global__ __launch_bounds__(THREADS) void layernorm_bwd_kernel(const bf16* __re
       }
     }
   }
+  if (ws) {
+    // ordered mode: every wave stores its sums to its own LDS vector, thread i adds the vectors in wave order and
+    // stores the workgroup's partial to slot blockIdx.x of the workspace; rvit_ordered_finalize adds the slots in order
+    constexpr int V = 2 * IT * 256;
+    float* mine = lnb_red + (threadIdx.x >> 6) * V;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int e = it * 256 + lane * 4;
+      *reinterpret_cast<float4*>(mine + e) = make_float4(dg[it][0], dg[it][1], dg[it][2], dg[it][3]);
+      *reinterpret_cast<float4*>(mine + IT * 256 + e) = make_float4(db[it][0], db[it][1], db[it][2], db[it][3]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < V; i += THREADS) {
+      float t = 0.f;
+      for (int w = 0; w < WAVES; ++w) t += lnb_red[w * V + i];
+      ws[(long)blockIdx.x * V + i] = t;
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int e = it * 256 + lane * 4;
@@ -115,9 +137,10 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
                                                       float* __restrict__ dlogits, long lddl,
                                                       bf16* __restrict__ dlogits_bf16, long lddb, int B, int C,
                                                       int C_pad, float eps, float gscale) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  // ONE workgroup loops over the batch, so the loss is summed in a fixed order (lanes by butterfly, waves in order)
+  __shared__ float ce_red[4];
   float li = 0.f;
-  if (i < B) {
+  for (int i = threadIdx.x; i < B; i += 256) {
     const float* z = logits + (long)i * ldl;
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
@@ -125,7 +148,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     for (int c = 0; c < C; ++c) { se += expf(z[c] - mx); sz += z[c]; }
     const float lse = mx + logf(se);
     const int y = (int)labels[i];
-    li = (1.f - eps) * (lse - z[y]) + eps * (lse - sz / (float)C);
+    li += (1.f - eps) * (lse - z[y]) + eps * (lse - sz / (float)C);
     const float un = eps / (float)C;
     for (int c = 0; c < C_pad; ++c) {
       float d = 0.f;
@@ -135,7 +158,9 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     }
   }
   li = wave_sum(li);
-  if ((threadIdx.x & 63) == 0 && loss_sum) atomicAdd(loss_sum, li / (float)B);
+  if ((threadIdx.x & 63) == 0) ce_red[threadIdx.x >> 6] = li;
+  __syncthreads();
+  if (threadIdx.x == 0 && loss_sum) *loss_sum += (((ce_red[0] + ce_red[1]) + ce_red[2]) + ce_red[3]) / (float)B;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -149,8 +174,10 @@ __device__ __forceinline__ long colsum_row(long m, long row_group, long row_extr
 }
 
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ a, long lda, float* __restrict__ out,
-                                                     long M, int N, long row_group, long row_extra) {
+                                                     long M, int N, long row_group, long row_extra,
+                                                     float* __restrict__ ws) {
   __shared__ float red[256];
+  __shared__ float slots[8][256];   // ordered mode: one vector per row lane
   red[threadIdx.x] = 0.f;
   __syncthreads();
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -189,8 +216,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ a,
           if (n0 + k < N) s[k] += (float)row[n0 + k];
       }
     }
+    if (!ws) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) atomicAdd(&red[tx * 8 + k], s[k]);
+      for (int k = 0; k < 8; ++k) atomicAdd(&red[tx * 8 + k], s[k]);
+    }
+  }
+  if (ws) {   // row lanes added in order, the workgroup's partial stored to slot blockIdx.y; finalised in slot order
+#pragma unroll
+    for (int k = 0; k < 8; ++k) slots[ty][tx * 8 + k] = s[k];
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += slots[r][threadIdx.x];
+    ws[((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x] = t;
+    return;
   }
   __syncthreads();
   const int n = blockIdx.x * 256 + threadIdx.x;
@@ -216,7 +255,8 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
 
 int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                             const float* gamma, float* dxs, long lddx, int accumulate, void* dx_bf16, long lddb,
-                            float* dgamma, float* dbeta, long rows, int E, hipStream_t st) {
+                            float* dgamma, float* dbeta, long rows, int E, float* ws, size_t ws_bytes,
+                            hipStream_t st) {
   RVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dxs && dgamma && dbeta, "layernorm_bwd: null pointer");
   RVIT_CHECK_ARG(E > 0 && (E & 3) == 0 && E <= LNB_MAX_IT * 256, "layernorm_bwd: E=%d unsupported", E);
   RVIT_CHECK_ARG((lddy & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0 && (!dx_bf16 || (lddb & 3) == 0),
@@ -230,12 +270,22 @@ int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx,
   const int threads = it <= 3 ? 1024 : 256;
   long blocks = (rows + threads / 64 - 1) / (threads / 64);
   if (blocks > 256) blocks = 256;
+  const int V = 2 * it * 256;   // floats of one partial vector: dgamma at [0, E), dbeta at [it * 256, it * 256 + E)
+  size_t lds = (size_t)V * sizeof(float);
+  if (ws) {
+    RVIT_CHECK_ARG(rvit_aligned16(ws) && ws_bytes >= (size_t)blocks * V * sizeof(float),
+                   "layernorm_bwd: the ordered-reduction workspace needs %zu bytes", (size_t)blocks * V * sizeof(float));
+    lds *= threads / 64;
+  }
 #define LNB_CASE(N, T)                                                                                          \
-  case N:                                                                                                       \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<N, T>), dim3((unsigned)blocks), dim3(T), 2 * N * 256 * sizeof(float), \
+  case N: {                                                                                                     \
+    static RvitLdsLimit lim;                                                                                    \
+    if (const int rc = lim.ensure({(const void*)layernorm_bwd_kernel<N, T>}, (int)lds, "layernorm_bwd")) return rc; \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<N, T>), dim3((unsigned)blocks), dim3(T), lds,                      \
                        st, (const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dxs, lddx, accumulate,             \
-                       (bf16*)dx_bf16, lddb, dgamma, dbeta, rows, E);                                           \
-    break;
+                       (bf16*)dx_bf16, lddb, dgamma, dbeta, rows, E, ws);                                       \
+    break;                                                                                                      \
+  }
   switch (it) {
     LNB_CASE(1, 1024) LNB_CASE(2, 1024) LNB_CASE(3, 1024) LNB_CASE(4, 256) LNB_CASE(5, 256) LNB_CASE(6, 256)
     LNB_CASE(7, 256) LNB_CASE(8, 256)
@@ -243,6 +293,10 @@ int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx,
   }
 #undef LNB_CASE
   RVIT_CHECK_LAUNCH("layernorm_bwd");
+  if (ws) {
+    if (const int rc = rvit_ordered_finalize(ws, (int)blocks, V, dgamma, 1, E, E, st)) return rc;
+    return rvit_ordered_finalize(ws + it * 256, (int)blocks, V, dbeta, 1, E, E, st);
+  }
   return RVIT_OK;
 }
 
@@ -251,14 +305,14 @@ int rvit_ce_loss_impl(const float* logits, long ldl, const long* labels, float* 
                       hipStream_t st) {
   RVIT_CHECK_ARG(logits && labels && B > 0 && C > 0 && C <= 4096 && C_pad >= C, "ce_loss: bad arguments");
   RVIT_CHECK_ARG(!dlogits_bf16 || lddb >= C_pad, "ce_loss: bf16 gradient pitch smaller than C_pad");
-  hipLaunchKernelGGL(ce_loss_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, logits, ldl, labels,
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(256), 0, st, logits, ldl, labels,
                      loss_sum, dlogits, lddl, (bf16*)dlogits_bf16, lddb, B, C, C_pad, eps, gscale);
   RVIT_CHECK_LAUNCH("ce_loss");
   return RVIT_OK;
 }
 
 int rvit_colsum_impl(const void* a, long lda, float* out, long M, int N, long row_group, long row_extra,
-                     hipStream_t st) {
+                     float* ws, size_t ws_bytes, hipStream_t st) {
   RVIT_CHECK_ARG(a && out && M >= 0 && N > 0 && lda >= N, "colsum: bad arguments");
   if (M == 0) return RVIT_OK;
   RVIT_CHECK_ARG(((uintptr_t)a & 15) == 0 || (lda & 7) != 0, "colsum: a must be 16-byte aligned");
@@ -266,9 +320,13 @@ int rvit_colsum_impl(const void* a, long lda, float* out, long M, int N, long ro
   long ysplit = (M + 63) / 64;
   const long cap = (256 + xb - 1) / xb;  // few workgroups: the column totals share one L2 channel's atomic unit
   if (ysplit > cap) ysplit = cap;
+  if (ws)
+    RVIT_CHECK_ARG(rvit_aligned16(ws) && ws_bytes >= (size_t)xb * ysplit * 256 * sizeof(float),
+                   "colsum: the ordered-reduction workspace needs %zu bytes", (size_t)xb * ysplit * 256 * sizeof(float));
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)xb, (unsigned)ysplit), dim3(256), 0, st,
-                     (const bf16*)a, lda, out, M, N, row_group, row_extra);
+                     (const bf16*)a, lda, out, M, N, row_group, row_extra, ws);
   RVIT_CHECK_LAUNCH("colsum");
+  if (ws) return rvit_ordered_finalize(ws, (int)ysplit, (long)xb * 256, out, 1, N, N, st);
   return RVIT_OK;
 }
 

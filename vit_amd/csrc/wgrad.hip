@@ -232,15 +232,23 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
 
   // ---- restage through LDS and add whole 256-byte rows atomically ---------------------------------
   // lane holds D[row n = 16i + 4g + r][col k = 16j + (lane&15)]
+  // ordered mode (p.part): this split's tile is STORED to its own slot of the workspace, rvit_ordered_finalize adds
+  // the slots in order afterwards; the wave groups that share an output tile (W8, NARROW) own a sub-slot each
+  constexpr int SUB = (NARROW || W8) ? 2 : 1;
+  const long slot = (long)split * SUB + (NARROW ? (wave >> 1) : W8 ? (wave >> 2) : 0);
   if constexpr (!GATHER && !NARROW) {
     if (with_bias && (lane & 15) < 4) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + 16 * (lane & 15) + 4 * g + r;
-        if (n < p.N_store) atomicAdd(p.dbias + n, bsum[r]);
+        if (n < p.N_store) {
+          if (p.part_bias) p.part_bias[slot * p.N_store + n] = bsum[r];
+          else atomicAdd(p.dbias + n, bsum[r]);
+        }
       }
     }
   }
+  float* const pslot = p.part ? p.part + slot * p.part_stride : nullptr;
   constexpr int EP = 64 * 4 + 16;  // fp32 row pitch of the wave-private staging area
   constexpr int EROWS = W16 ? 16 : 32;  // rows staged per pass (sixteen waves x 32 rows would not fit the ring)
   char* ep = smem + wave * (EROWS * EP);
@@ -261,7 +269,8 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
       const int n = n0 + wn * 64 + part * EROWS + row;
       if (n < p.N_store && k < p.K) {
         const float v = *reinterpret_cast<const float*>(ep + row * EP + lane * 4);
-        atomicAdd(p.dW + (long)n * p.ldw + k, v);
+        if (pslot) pslot[(long)n * p.K + k] = v;
+        else atomicAdd(p.dW + (long)n * p.ldw + k, v);
       }
     }
     __syncthreads();
@@ -269,6 +278,26 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
 }
 
 }  // namespace
+
+// Ordered mode: carve the caller's workspace into `sub` slots per split for the weight tile partials (+ the bias sums),
+// limit the split count to what fits and make every split non-empty.
+static int wgrad_ordered_setup(WgradArgs& o, long units, int sub, long* splits) {
+  const long elems = (long)o.N_store * o.K + (o.dbias ? o.N_store : 0);
+  RVIT_CHECK_ARG(rvit_aligned16(o.ws), "wgrad: the ordered-reduction workspace must be 16-byte aligned");
+  if (const int rc = rvit_ordered_splits(units, *splits, sub, (elems + 3) & ~3L, o.ws_bytes, "wgrad", splits)) return rc;
+  o.part_sub = sub;
+  o.part = o.ws;
+  o.part_stride = (((long)o.N_store * o.K) + 3) & ~3L;
+  o.part_bias = o.dbias ? o.ws + *splits * sub * o.part_stride : nullptr;
+  return RVIT_OK;
+}
+static int wgrad_ordered_finish(const WgradArgs& o, int splits, hipStream_t st) {
+  if (!o.part) return RVIT_OK;
+  const int nslots = splits * o.part_sub;
+  if (const int rc = rvit_ordered_finalize(o.part, nslots, o.part_stride, o.dW, o.N_store, o.K, o.ldw, st)) return rc;
+  if (o.part_bias) return rvit_ordered_finalize(o.part_bias, nslots, o.N_store, o.dbias, 1, o.N_store, o.N_store, st);
+  return RVIT_OK;
+}
 
 int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
   RVIT_CHECK_ARG(a.dY && a.X && a.dW, "wgrad: null pointer");
@@ -314,15 +343,19 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
     if (sp < 1) sp = 1;
     const bool pays = a.N >= 256 && a.K >= 256 && (mtiles + sp - 1) / sp >= 12;
     if (a.splits == -3 || pays) {
+      WgradArgs o = a;
+      if (a.ws) {
+        if (const int rc = wgrad_ordered_setup(o, mtiles, 1, &sp)) return rc;
+      }
       RVIT_CHECK_ARG(tiles16 * sp < 0x7fffffffL, "wgrad: too many workgroups");
       const size_t lds16 = 2 * 4 * TILE_B;  // 128 KB
       static RvitLdsLimit lim16;
       if (const int rc = lim16.ensure({(const void*)wgrad_bf16_kernel<false, false, false, true>}, (int)lds16, "wgrad(w16)"))
         return rc;
-      hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, false, true>), dim3((unsigned)(tiles16 * sp)), dim3(1024), lds16, st, a,
+      hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, false, true>), dim3((unsigned)(tiles16 * sp)), dim3(1024), lds16, st, o,
                          (int)tiles16, (int)sp);
       RVIT_CHECK_LAUNCH("wgrad_bf16");
-      return RVIT_OK;
+      return wgrad_ordered_finish(o, (int)sp, st);
     }
   }
   const long tiles = (long)((a.N + 127) / 128) * ((a.K + 127) / 128);
@@ -334,14 +367,21 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
   if (a.splits <= 0 && splits > (mtiles + 3) / 4) splits = (mtiles + 3) / 4;
   if (splits > mtiles) splits = mtiles;
   if (splits < 1) splits = 1;
+  const bool narrow = a.N <= 64;
+  WgradArgs o = a;
+  if (a.ws) {
+    // the variant (and with it the sub-slot count) depends on the split count: settle the splits for two sub-slots
+    // when the first guess selects a two-group variant, then keep that variant
+    const bool two = narrow || (a.mode == 0 && (mtiles + splits - 1) / splits >= 32);
+    if (const int rc = wgrad_ordered_setup(o, mtiles, two ? 2 : 1, &splits)) return rc;
+  }
   RVIT_CHECK_ARG(tiles * splits < 0x7fffffffL, "wgrad: too many workgroups");
   const size_t lds = 2 * 2 * TILE_B;  // 64 KB
   dim3 grid((unsigned)(tiles * splits));
-  const bool narrow = a.N <= 64;
   // Eight waves pay when a workgroup owns a long M range (ViT-B/L Linears: 20.2 vs 21.9 ms of weight gradients per
   // ViT-B step); with few M tiles per split the doubled epilogue atomics cost more than the main loop gains
   // (the E=256 encoder: 46 -> 71 us), and the gather variants gain nothing.
-  const bool w8 = a.mode == 0 && (mtiles + splits - 1) / splits >= 32;
+  const bool w8 = a.mode == 0 && (mtiles + splits - 1) / splits >= 32 && (!a.ws || o.part_sub == 2);
   if (!narrow && w8) {
     // eight waves: the wave-private epilogue staging (8 x 32 rows x 272 B) is what sizes the LDS
     const size_t lds8 = 8 * 32 * (64 * 4 + 16);
@@ -349,15 +389,16 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
     if (const int rc = lim8.ensure({(const void*)wgrad_bf16_kernel<true, false, true>,
                                     (const void*)wgrad_bf16_kernel<false, false, true>}, (int)lds8, "wgrad(w8)"))
       return rc;
-    if (a.mode == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, true>), grid, dim3(512), lds8, st, a, (int)tiles, (int)splits);
-    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, true>), grid, dim3(512), lds8, st, a, (int)tiles, (int)splits);
+    if (a.mode == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, true>), grid, dim3(512), lds8, st, o, (int)tiles, (int)splits);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, true>), grid, dim3(512), lds8, st, o, (int)tiles, (int)splits);
   } else if (a.mode == 1) {
-    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
-    else hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true, false>), grid, dim3(256), lds, st, o, (int)tiles, (int)splits);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, false>), grid, dim3(256), lds, st, o, (int)tiles, (int)splits);
   } else {
-    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
-    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, false>), grid, dim3(256), lds, st, a, (int)tiles, (int)splits);
+    if (narrow) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true, false>), grid, dim3(256), lds, st, o, (int)tiles, (int)splits);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, false>), grid, dim3(256), lds, st, o, (int)tiles, (int)splits);
   }
   RVIT_CHECK_LAUNCH("wgrad_bf16");
-  return RVIT_OK;
+  // a variant with one wave group per tile leaves the second sub-slot of a two-sub-slot layout unwritten: it is not read
+  return wgrad_ordered_finish(o, (int)splits, st);
 }

@@ -52,6 +52,8 @@ struct W3Args {
   int ntiles;       // ceil(M / tile_len)
   int nsplits;      // workgroups per (co, ci) pair
   int patch_bytes;  // bytes of the patch part of one ring stage (multiple of 1024); the dY tile follows it
+  float* part;      // ordered mode: split s stores its [Cout][9 Cin] partial at part + s * part_stride (no atomics)
+  long part_stride;
 };
 
 // ALIGNED: tiles are whole image rows (tile_len = rows * W, rows | H).  Then every tile has the same patch shape and
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(64 * WD_WAVES, 1) void conv3x3_wgrad_direct_kernel(
   constexpr int EP = 64 * 4 + 16;
   char* ep = smem + wave * (16 * EP);
   const long ldw = 9L * Cin;
+  float* const dst = p.part ? p.part + (long)split * p.part_stride : p.dW;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -282,7 +285,9 @@ __global__ __launch_bounds__(64 * WD_WAVES, 1) void conv3x3_wgrad_direct_kernel(
 #pragma unroll 4
     for (int row = 0; row < 16; ++row) {
       const float v = *reinterpret_cast<const float*>(ep + row * EP + lane * 4);
-      atomicAdd(p.dW + (long)(co0 + i * 16 + row) * ldw + wave * Cin + ci0 + lane, v);
+      float* q = dst + (long)(co0 + i * 16 + row) * ldw + wave * Cin + ci0 + lane;
+      if (p.part) *q = v;
+      else atomicAdd(q, v);
     }
     __syncthreads();
   }
@@ -327,6 +332,15 @@ int rvit_conv3x3_wgrad_direct(const WgradArgs& a, hipStream_t st) {
   int splits = a.splits > 0 ? a.splits : (256 + pairs - 1) / pairs;
   if (splits > (p.ntiles + 3) / 4) splits = (p.ntiles + 3) / 4;
   if (splits < 1) splits = 1;
+  p.part = nullptr;
+  p.part_stride = (long)a.N * a.K;
+  if (a.ws) {
+    RVIT_CHECK_ARG(rvit_aligned16(a.ws), "conv3x3 wgrad: the ordered-reduction workspace must be 16-byte aligned");
+    long sp = splits;
+    if (const int rc = rvit_ordered_splits(p.ntiles, sp, 1, p.part_stride, a.ws_bytes, "conv3x3 wgrad", &sp)) return rc;
+    splits = (int)sp;
+    p.part = a.ws;
+  }
   p.nsplits = splits;
   p.patch_bytes = ((w3_patch_pixels(a.H, a.W, p.tile_len) + 7) / 8) * 1024;
   const int lds = WD_STAGES * (p.patch_bytes + WD_TL * 128) + 1024;
@@ -338,5 +352,6 @@ int rvit_conv3x3_wgrad_direct(const WgradArgs& a, hipStream_t st) {
   if (aligned) hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel<true>, dim3((unsigned)(pairs * splits)), dim3(64 * WD_WAVES), lds, st, p);
   else hipLaunchKernelGGL(conv3x3_wgrad_direct_kernel<false>, dim3((unsigned)(pairs * splits)), dim3(64 * WD_WAVES), lds, st, p);
   RVIT_CHECK_LAUNCH("conv3x3_wgrad_direct");
+  if (p.part) return rvit_ordered_finalize(p.part, splits, p.part_stride, a.dW, a.N, a.K, a.ldw, st);
   return RVIT_OK;
 }

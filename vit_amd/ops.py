@@ -105,6 +105,33 @@ def _drop(drop):
     return _DROP_POS[pos], float(p), int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
+# Ordered (bit-reproducible) reductions: one scratch workspace per device, handed to every entry point that would
+# otherwise end a split reduction in fp32 atomics (include/rvit.h "Ordered reductions").  The training engine enables
+# it; calls that share the workspace must be ordered on one stream (they are: the engine's compute stream).
+ORDERED_WORKSPACE_BYTES = 192 << 20
+_ORDERED_WS: dict = {}
+
+
+def enable_ordered_reductions(device, enable: bool = True, nbytes: int = ORDERED_WORKSPACE_BYTES) -> None:
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if not enable:
+        _ORDERED_WS.pop(idx, None)
+    elif idx not in _ORDERED_WS or _ORDERED_WS[idx].numel() < nbytes:
+        _ORDERED_WS[idx] = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+
+
+def ordered_reductions_enabled(device) -> bool:
+    dev = torch.device(device)
+    return (dev.index if dev.index is not None else torch.cuda.current_device()) in _ORDERED_WS
+
+
+def _ows(t: torch.Tensor):
+    """(pointer, bytes) of the ordered-reduction workspace of t's device, or (None, 0)."""
+    w = _ORDERED_WS.get(t.device.index)
+    return (w.data_ptr(), w.numel()) if w is not None else (None, 0)
+
+
 def _vec_f32(v, n, what):
     if v is not None and (v.dtype != torch.float32 or v.numel() != n or not v.is_contiguous()):
         raise ValueError(f"{what} must be contiguous float32 [{n}]")
@@ -551,7 +578,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, rows: Optional
         raise ValueError(f"wgrad: bad operands dy{tuple(dy.shape)} x{tuple(x.shape)} dw{tuple(dw.shape)}")
     with _Span("wgrad_bf16", 2 * M * N * K, (M * N + M * K) * 2 + n_store * K * 4):
         check(_lib.load().rvit_wgrad_bf16(dy.data_ptr(), ldy, y_row_group, y_row_extra, x.data_ptr(), ldx, x_row_group,
-                                          x_row_extra, dw.data_ptr(), ldw, M, N, n_store, K, splits, _stream()),
+                                          x_row_extra, dw.data_ptr(), ldw, M, N, n_store, K, splits, *_ows(dw), _stream()),
               "rvit_wgrad_bf16")
     return dw
 
@@ -570,7 +597,7 @@ def linear_wgrad_bias(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dbias
     _vec_f32(dbias, n_store, "linear_wgrad_bias: dbias")
     with _Span("wgrad_bf16", 2 * M * N * K, (M * N + M * K) * 2 + n_store * K * 4):
         check(_lib.load().rvit_linear_wgrad_bias_bf16(dy.data_ptr(), ldy, x.data_ptr(), ldx, dw.data_ptr(), ldw,
-                                                      dbias.data_ptr(), M, N, n_store, K, splits, _stream()),
+                                                      dbias.data_ptr(), M, N, n_store, K, splits, *_ows(dw), _stream()),
               "rvit_linear_wgrad_bias_bf16")
     return dw
 
@@ -587,7 +614,7 @@ def conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, kh: int
         raise ValueError("conv2d_wgrad: bad operands")
     with _Span("conv2d_wgrad", 2 * B * Ho * Wo * Cout * kh * kw * seg, _nbytes(dy, x, dw)):
         check(_lib.load().rvit_conv2d_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, Cpix, seg, kh, kw,
-                                                 stride, pad, Ho, Wo, Cout, splits, _stream()),
+                                                 stride, pad, Ho, Wo, Cout, splits, *_ows(dw), _stream()),
               "rvit_conv2d_wgrad_bf16")
     return dw
 
@@ -668,7 +695,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: t
     with _Span("layernorm_bwd", 0, rows * E * (2 + 4 + 8 + (2 if dx_bf16 is not None else 0))):
         check(_lib.load().rvit_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, mean.data_ptr(), rstd.data_ptr(),
                                              gamma.data_ptr(), dx.data_ptr(), lddx, int(accumulate), _ptr(dx_bf16),
-                                             lddb, dgamma.data_ptr(), dbeta.data_ptr(), rows, E, _stream()),
+                                             lddb, dgamma.data_ptr(), dbeta.data_ptr(), rows, E, *_ows(dx), _stream()),
               "rvit_layernorm_bwd")
     return dx
 
@@ -729,7 +756,8 @@ def colsum(a: torch.Tensor, out: torch.Tensor, *, rows: Optional[int] = None, ro
         raise TypeError("colsum: a must be bf16")
     _vec_f32(out, N, "colsum: out")
     with _Span("colsum", 0, M * N * 2):
-        check(_lib.load().rvit_colsum_bf16(a.data_ptr(), lda, out.data_ptr(), M, N, row_group, row_extra, _stream()),
+        check(_lib.load().rvit_colsum_bf16(a.data_ptr(), lda, out.data_ptr(), M, N, row_group, row_extra, *_ows(out),
+                                           _stream()),
               "rvit_colsum_bf16")
     return out
 
@@ -886,7 +914,7 @@ def sumsq(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     if x.dtype != torch.float32 or out.dtype != torch.float32 or not x.is_contiguous():
         raise ValueError("sumsq: contiguous float32 expected")
     with _Span("grad_sumsq", 0, x.numel() * 4):
-        check(_lib.load().rvit_sumsq_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "rvit_sumsq_f32")
+        check(_lib.load().rvit_sumsq_f32(_ptr(x), x.numel(), _ptr(out), *_ows(out), _stream()), "rvit_sumsq_f32")
     return out
 
 

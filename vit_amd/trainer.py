@@ -232,6 +232,11 @@ class TrainEngine:
         # float-atomic form (a few percent faster on the small maps, last bits vary).
         import os
         self.ordered_bn = os.environ.get("RVIT_BN_ORDERED", "1") != "0"
+        # ... and every other split reduction of the step (weight / bias gradients, LayerNorm affine gradients, the
+        # gradient norm): partials stored per split and added in order (ops.enable_ordered_reductions; one 192 MB
+        # scratch workspace per device).  With both on, two runs of a step give the same bits in every gradient and
+        # parameter.  RVIT_ORDERED=0 selects the float-atomic forms.
+        self.ordered = os.environ.get("RVIT_ORDERED", "1") != "0"
 
     # ---- data parallel -------------------------------------------------------------------------
     def set_data_parallel(self, process_group=None, bucket_mb: float = 8.0) -> None:
@@ -306,6 +311,7 @@ class TrainEngine:
 
     # ---- buffers -----------------------------------------------------------------------------------
     def buffers(self, B: int, dev) -> dict:
+        ops.enable_ordered_reductions(dev, self.ordered)
         b = self._bufs.get(B)
         if b is not None and b["dev"] == dev:
             return b
