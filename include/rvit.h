@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 14
+#define RVIT_ABI_VERSION 15
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -265,6 +265,13 @@ int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx
  *   ((b*H + h)*S + query)*S + key. */
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
                   float drop_p, uint64_t drop_seed, void* stream);
+
+/* rvit_attn_fwd (no dropout, no lse) for S <= 64 with the arithmetic of rvit_encoder_attn_fwd's attention core: the
+ * per-op sequence rvit_layernorm_fwd -> rvit_gemm_bf16 -> rvit_attn_fwd_s64 -> rvit_gemm_bf16(residual) gives the SAME
+ * BITS as rvit_encoder_attn_fwd, so a caller may choose between them by batch size (the fused kernel needs a few
+ * hundred images to fill the chip) without a frame's result depending on the batch it travels in. */
+int rvit_attn_fwd_s64(const void* qkv, void* out, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
+                      void* stream);
 
 /* rvit_attn_fwd for the MX-fp8 inference mode (BASELINE.json configs[4]): both products run on the fp8 MFMA and the
  * result is emitted as the MXFP8 operand of the out_proj GEMM (no bf16 attention map, no quantisation pass).

@@ -331,6 +331,123 @@ __device__ __forceinline__ int k_off128(int row, int chunk) { return row * 128 +
 constexpr int EN_VT_PITCH = 272;  // bytes per V^T row: 128 tokens + 16: rows 4 banks apart, 8-byte accesses conflict-free
 constexpr int EN_ATTN_LDS = 128 * 512 + 3 * 128 * 128 + 64 * EN_VT_PITCH;
 
+// Attention core shared by enc_attn_kernel and attn16_kernel (same source, same bits): one wave = 16 queries of one
+// (image, head).  sQ / sK: token-major 128-byte rows (k_off128), this image's rows start at `row0`, the wave's query
+// row is `rowq`; vt: V^T of this image, row d at vt + d * VT_PITCH, key t at byte 2 t.  S^T = K Q^T with keys on the
+// accumulator rows, softmax over the lane's 16 keys and the three lanes that hold the other keys of its query, the
+// probabilities fed back from the accumulator registers as the "B" operand of O^T = V^T P^T (the 8 keys a lane holds
+// per MFMA step are two runs of 4, read from V^T as the same two 8-byte runs).  w[dt]: 4 consecutive output columns
+// 16 dt + 4 fq .. of the wave's query row fr, normalised, bf16.
+template <int VT_PITCH>
+__device__ __forceinline__ void attn16_core(const char* sQ, const char* sK, const char* vt, int row0, int rowq, int fr, int fq,
+                                            int S, float scale_log2e, uint2 (&w)[4]) {
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = lds_frag(sQ + k_off128(rowq, ks * 4 + fq));
+  f32x4 sc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 kf = lds_frag(sK + k_off128(row0 + kt * 16 + fr, ks * 4 + fq));
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[kt], 0, 0, 0);
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (kt * 16 + fq * 4 + e >= S) sc[kt][e] = -INFINITY;
+      mx = fmaxf(mx, sc[kt][e]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pe = __builtin_amdgcn_exp2f(__fmul_rn(__fsub_rn(sc[kt][e], mx), scale_log2e));
+      sc[kt][e] = pe;
+      sum = __fadd_rn(sum, pe);
+    }
+  sum = __fadd_rn(sum, __shfl_xor(sum, 16, 64));
+  sum = __fadd_rn(sum, __shfl_xor(sum, 32, 64));
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    bf16x8 pb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pb[e] = (bf16)sc[2 * kk][e];
+      pb[4 + e] = (bf16)sc[2 * kk + 1][e];
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const char* vrow = vt + (dt * 16 + fr) * VT_PITCH + fq * 8;
+      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + (2 * kk) * 32);
+      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (2 * kk + 1) * 32);
+      bf16x8 vf;
+      vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+      vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb, o[dt], 0, 0, 0);
+    }
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    w[dt].x = pack_bf16x2(__fmul_rn(o[dt][0], inv), __fmul_rn(o[dt][1], inv));
+    w[dt].y = pack_bf16x2(__fmul_rn(o[dt][2], inv), __fmul_rn(o[dt][3], inv));
+  }
+}
+
+// The attention of the per-op path for S <= 64 (small batches, where the fused kernel's one workgroup per two images
+// cannot fill the chip): one workgroup of four waves per (image, head), q / k / v read from the in_proj output
+// [T, 3E], the core above, output bf16 [T, E].  Same bits as enc_attn_kernel's phase 2, so the engine may pick
+// either path by batch size without a frame's logits depending on the batch it travels in.
+constexpr int A16_VT_PITCH = 144;  // 64 keys + 16 bytes: rows 36 banks apart, 8-byte accesses conflict-free
+__global__ __launch_bounds__(256) void attn16_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int S, int H,
+                                                     long ldq, long ldo, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) char sQ[64 * 128];
+  __shared__ __attribute__((aligned(16))) char sK[64 * 128];
+  __shared__ __attribute__((aligned(16))) char sVt[64 * A16_VT_PITCH];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int E = H * 64;
+  const bf16* base = qkv + (long)b * S * ldq + h * 64;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int id = t + it * 256, row = id >> 3, c = id & 7;
+    uint4 q4 = make_uint4(0, 0, 0, 0), k4 = q4, v4 = q4;
+    if (row < S) {
+      const bf16* p = base + (long)row * ldq + c * 8;
+      q4 = *reinterpret_cast<const uint4*>(p);
+      k4 = *reinterpret_cast<const uint4*>(p + E);
+      v4 = *reinterpret_cast<const uint4*>(p + 2 * E);
+    }
+    *reinterpret_cast<uint4*>(sQ + k_off128(row, c)) = q4;
+    *reinterpret_cast<uint4*>(sK + k_off128(row, c)) = k4;
+    const unsigned short* ve = reinterpret_cast<const unsigned short*>(&v4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short*>(sVt + (c * 8 + e) * A16_VT_PITCH + row * 2) = ve[e];
+  }
+  __syncthreads();
+  if (wave * 16 >= S) return;
+  const int rowq = wave * 16 + fr;
+  uint2 w[4];
+  attn16_core<A16_VT_PITCH>(sQ, sK, sVt, 0, rowq, fr, fq, S, scale_log2e, w);
+  if (rowq < S) {
+    bf16* orow = out + ((long)b * S + rowq) * ldo + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<uint2*>(orow + dt * 16 + fq * 4) = w[dt];
+  }
+}
+
 __global__ __launch_bounds__(EN_THREADS) void enc_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
                                                               const bf16* __restrict__ wqkv, const float* __restrict__ bqkv,
@@ -447,70 +564,11 @@ __global__ __launch_bounds__(EN_THREADS) void enc_attn_kernel(float* __restrict_
     // ---- phase 2: queries 16 wn .. + 15 of image wm ------------------------------------------------------------
     {
       const int rowq = wm * 64 + wn * 16 + fr;
-      bf16x8 qf[2];
+      uint2 w[4];
+      attn16_core<EN_VT_PITCH>(sQ, sK, sVt + wm * 128, wm * 64, rowq, fr, fq, S, scale_log2e, w);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) qf[ks] = lds_frag(sQ + k_off128(rowq, ks * 4 + fq));
-      f32x4 sc[4];
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 kf = lds_frag(sK + k_off128(wm * 64 + kt * 16 + fr, ks * 4 + fq));
-          sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[kt], 0, 0, 0);
-        }
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (kt * 16 + fq * 4 + e >= S) sc[kt][e] = -INFINITY;
-          mx = fmaxf(mx, sc[kt][e]);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pe = __builtin_amdgcn_exp2f((sc[kt][e] - mx) * scale_log2e);
-          sc[kt][e] = pe;
-          sum += pe;
-        }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
-      f32x4 o[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        bf16x8 pb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pb[e] = (bf16)sc[2 * kk][e];
-          pb[4 + e] = (bf16)sc[2 * kk + 1][e];
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const char* vrow = sVt + (dt * 16 + fr) * EN_VT_PITCH + (wm * 64 + fq * 4) * 2;
-          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow + (2 * kk) * 32);
-          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + (2 * kk + 1) * 32);
-          bf16x8 vf;
-          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-          vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb, o[dt], 0, 0, 0);
-        }
-      }
-      const float inv = 1.0f / sum;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        uint2 w;
-        w.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
-        w.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
-        *reinterpret_cast<uint2*>(sO + k_off128(rowq, dt * 2 + (fq >> 1)) + (fq & 1) * 8) = w;
-      }
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(sO + k_off128(rowq, dt * 2 + (fq >> 1)) + (fq & 1) * 8) = w[dt];
     }
     __syncthreads();
 
@@ -605,5 +663,17 @@ int rvit_encoder_attn_impl(float* x, const float* gamma, const float* beta, floa
   hipLaunchKernelGGL(enc_attn_kernel, dim3((unsigned)((B + 1) / 2)), dim3(EN_THREADS), EN_ATTN_LDS, st, x, gamma, beta, eps,
                      (const bf16*)wqkv, bqkv, (const bf16*)wout, bout, B, S, 0.125f * 1.44269504088896340736f);
   RVIT_CHECK_LAUNCH("encoder_attn");
+  return RVIT_OK;
+}
+
+int rvit_attn16_impl(const void* qkv, void* out, int B, int S, int H, long ldq, long ldo, float scale, hipStream_t st) {
+  RVIT_CHECK_ARG(qkv && out, "attn_fwd_s64: null pointer");
+  RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 64, "attn_fwd_s64: unsupported shape B=%d H=%d S=%d (S<=64)", B, H, S);
+  RVIT_CHECK_ARG(ldq >= 3L * H * 64 && (ldq & 7) == 0 && ldo >= (long)H * 64 && (ldo & 3) == 0,
+                 "attn_fwd_s64: bad pitches ldq=%ld ldo=%ld", ldq, ldo);
+  RVIT_CHECK_ARG(rvit_aligned16(qkv) && ((uintptr_t)out & 7) == 0 && (long)B * H < 0x7fffffffL, "attn_fwd_s64: alignment / size");
+  hipLaunchKernelGGL(attn16_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, S, H, ldq, ldo,
+                     scale * 1.44269504088896340736f);
+  RVIT_CHECK_LAUNCH("attn_fwd_s64");
   return RVIT_OK;
 }

@@ -57,6 +57,7 @@ class Engine:
         self.precision = "bf16"
         # fused encoder-layer kernels where the shape allows (RVIT_ENCODER_FUSED=0: the per-op path, for A/B runs)
         self.fused_encoder = os.environ.get("RVIT_ENCODER_FUSED", "1") != "0"
+        self.FUSED_MIN_TOKENS = int(os.environ.get("RVIT_FUSED_MIN_TOKENS", "12800"))
         self.graph_max_batch = 0
 
     def set_precision(self, precision: str) -> None:
@@ -225,15 +226,24 @@ class Engine:
             ops.gemm_mx(b["hid_q"], b["hid_s"], L["fc2_w_q"], L["fc2_w_s"], x2, bias=L["fc2_b"], residual=x2)
             return
         # E = 256: each half of the layer is ONE kernel that keeps its tokens on the CU from the LayerNorm to the
-        # residual add (csrc/encoder.hip); the choice depends on the model's shape only, never on the batch
-        if self.fused_encoder and ops.encoder_attn_supported(E, H, S):
+        # residual add (csrc/encoder.hip).  One workgroup per CU owns ~100 tokens / two images, so the fused kernels
+        # need a few hundred images to fill the chip: below FUSED_MIN_TOKENS the per-op sequence is faster (B = 64:
+        # 0.97 vs 1.09 ms per forward; B = 1: 0.62 vs 0.77 ms).  Both paths give the SAME BITS (the per-op attention
+        # then is attention_s64, the fused kernel's core as a kernel of its own), so the choice by batch size does not
+        # make a frame's logits depend on the batch it travels in (tests/test_encoder_gpu.py, test_model_gpu.py).
+        shape_ok = ops.encoder_attn_supported(E, H, S) and ops.encoder_mlp_supported(E, L["fc1_w"].shape[0])
+        fused = self.fused_encoder and shape_ok and B * S >= self.FUSED_MIN_TOKENS
+        if fused:
             ops.encoder_attn(x2, L["ln1_w"], L["ln1_b"], L["qkv_w"], L["qkv_b"], L["out_w"], L["out_b"], B, S, H, L["eps1"])
         else:
             ops.layernorm(x2, L["ln1_w"], L["ln1_b"], b["ln"], L["eps1"])
             ops.gemm(b["ln"], L["qkv_w"], b["qkv"], bias=L["qkv_b"])
-            ops.attention(b["qkv"], b["att"], B, S, H)
+            if shape_ok:
+                ops.attention_s64(b["qkv"], b["att"], B, S, H)
+            else:
+                ops.attention(b["qkv"], b["att"], B, S, H)
             ops.gemm(b["att"], L["out_w"], x2, bias=L["out_b"], residual=x2)
-        if self.fused_encoder and ops.encoder_mlp_supported(E, L["fc1_w"].shape[0]):
+        if fused:
             ops.encoder_mlp(x2, L["ln2_w"], L["ln2_b"], L["fc1_w"], L["fc1_b"], L["fc2_w"], L["fc2_b"], L["eps2"])
         else:
             ops.layernorm(x2, L["ln2_w"], L["ln2_b"], b["ln"], L["eps2"])

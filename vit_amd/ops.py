@@ -542,6 +542,20 @@ def encoder_mlp_supported(E: int, hidden: int) -> bool:
     return E == 256 and hidden > 0 and hidden % 256 == 0
 
 
+def attention_s64(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, scale: Optional[float] = None) -> torch.Tensor:
+    """attention() for S <= 64 with the arithmetic of encoder_attn's core (bit-identical to the fused kernel)."""
+    _need_cuda(qkv, out)
+    T, W3, ldq = _rows2d(qkv, "attention_s64 qkv")
+    To, Wo, ldo = _rows2d(out, "attention_s64 out")
+    if T != B * S or To != T or W3 != 3 * H * 64 or Wo != H * 64 or S > 64 or qkv.dtype != BF16 or out.dtype != BF16:
+        raise ValueError(f"attention_s64: shapes {tuple(qkv.shape)} / {tuple(out.shape)} do not match B={B} S={S} H={H} (bf16, S <= 64)")
+    sc = (1.0 / 8.0) if scale is None else float(scale)
+    with _Span("attn_fwd", 4 * B * H * S * S * 64, _nbytes(qkv, out)):
+        check(_lib.load().rvit_attn_fwd_s64(qkv.data_ptr(), out.data_ptr(), B, S, H, ldq, ldo, sc, _stream()),
+              "rvit_attn_fwd_s64")
+    return out
+
+
 def attention_fp8(qkv: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, B: int, S: int, H: int,
                   scale: Optional[float] = None):
     """fp8-MFMA attention with MXFP8 output: qkv bf16 [B*S, 3*H*64]; out_q uint8 [B*S, H*64] (e4m3), out_s the tiled
