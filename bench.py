@@ -191,7 +191,7 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
             "ms_per_step": round(dt / args.train_steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_host / args.train_steps * 1e3, 3), "steps": args.train_steps,
             "batch_per_gpu": B,
-            "global_batch": world * B, "dropout": cfg["dropout"], "final_loss": round(float(loss), 4),
+            "global_batch": world * B, "dropout": cfg["dropout"], "final_loss": round(float(loss.detach()), 4),
             "includes": "forward(train-mode BN) + CE(label_smoothing=0.05) + backward + "
                         + ("bucketed RCCL all-reduce + " if world > 1 else "") + ("librvit fused clip+AdamW" if fused else "clip_grad_norm_ + torch AdamW(fused=True)"),
             "model_tflops": round(sps * 3 * fwd_flops / 1e12, 2),

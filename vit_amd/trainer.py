@@ -389,13 +389,19 @@ class TrainEngine:
     def _bn_params(self, bn):
         return bn.weight.detach(), bn.bias.detach()
 
+    def _bn_counters(self):
+        mods = self.__dict__.get("_bn_mods")
+        if mods is None:
+            mods = [mod for mod in self.m.cnn_backbone.modules() if hasattr(mod, "num_batches_tracked")]
+            self.__dict__["_bn_mods"] = mods
+        return [mod.num_batches_tracked for mod in mods]   # looked up per step: .to() replaces the buffers
+
     def _conv_bn(self, x, w, y, z, bn, fs, *, kh, stride, pad, relu, residual=None, seg_len=None, kw=None, mask=None,
                  ws=None):
         ops.conv2d(x, w, y, kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, seg_len=seg_len)
         ops.bn_stats(y, fs, ws)
         ops.bn_apply(y, fs, bn.weight.detach(), bn.bias.detach(), z, eps=bn.eps, relu=relu, residual=residual,
                      momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, relu_mask=mask)
-        bn.num_batches_tracked += 1
 
     def _stem_forward(self, P, b, B) -> torch.Tensor:
         cb = self.m.cnn_backbone
@@ -410,7 +416,6 @@ class TrainEngine:
         ops.bn_apply_pool(b["c1_y"], fs[off:off + 128], cb.bn1.weight.detach(), cb.bn1.bias.detach(), b["pool"],
                           b["pool_arg"], b["c1_m"], eps=cb.bn1.eps, momentum=cb.bn1.momentum,
                           running_mean=cb.bn1.running_mean, running_var=cb.bn1.running_var)
-        cb.bn1.num_batches_tracked += 1
         off += 128
         cur = b["pool"]
         for blk, pk, d in zip(cb.blocks(), P["blocks"], b["blocks"]):
@@ -429,6 +434,9 @@ class TrainEngine:
                           relu=True, residual=idn, mask=d["mo"], ws=ws)
             off += 2 * co * (2 if "ds_w" in pk else 1)
             cur = d["zo"]
+        # BatchNorm2d.num_batches_tracked += 1 for every norm of the stem (timm BatchNorm2d in train()): one fused launch
+        # instead of twenty
+        torch._foreach_add_(self._bn_counters(), 1)
         return cur
 
     def forward(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
