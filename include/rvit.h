@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 15
+#define RVIT_ABI_VERSION 16
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -32,6 +32,8 @@ extern "C" {
 #define RVIT_ACT_NONE 0
 #define RVIT_ACT_RELU 1
 #define RVIT_ACT_GELU 2 /* exact erf form, nn.GELU() / activation='gelu' */
+#define RVIT_ACT_HSWISH 3   /* x * relu6(x + 3) / 6  (nn.Hardswish; timm mobilenetv3) */
+#define RVIT_ACT_HSIGMOID 4 /* relu6(x + 3) / 6      (timm hard_sigmoid: the squeeze-excite gate of mobilenetv3) */
 
 #define RVIT_GATE_GELU_GRAD 1 /* value *= gelu'(gate)   (backward of nn.GELU) */
 #define RVIT_GATE_RELU_MASK 2 /* value *= (gate > 0)    (backward of ReLU)    */
@@ -172,6 +174,18 @@ int rvit_linear_wgrad_bias_bf16(const void* dY, int64_t ldy, const void* X, int6
 int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int H, int W, int Cpix, int seg_len,
                            int KH, int KW, int stride, int pad, int Ho, int Wo, int Cout, int splits, void* workspace,
                            int64_t workspace_bytes, void* stream);
+
+/* MobileNetV3 stem pieces (the reference's backbone='mobilenetv3' = timm mobilenetv3_small_100 features_only,
+ * train_vit.py:68-74,87,145-146; inference), NHWC bf16 maps, C % 8 == 0.  Pointwise convolutions and the squeeze-excite
+ * projections are rvit_gemm_bf16 over the same maps.
+ *   rvit_dwconv_fwd_bf16: depthwise K x K (K 3 or 5, stride 1 or 2) + folded BatchNorm (scale, bias) + activation;
+ *     w: bf16 [K*K, C] (tap-major); out [B, Ho, Wo, C].
+ *   rvit_avgpool_nhwc: out[b, c] = mean over the HW pixels (bf16 [B, C]).
+ *   rvit_channel_scale_nhwc: x[b, p, c] *= gate[b, c] in place (bf16 gate [B, C]). */
+int rvit_dwconv_fwd_bf16(const void* x, const void* w, const float* scale, const float* bias, void* out, int B, int H,
+                         int W, int C, int K, int stride, int pad, int act, void* stream);
+int rvit_avgpool_nhwc(const void* x, void* out, int B, int HW, int C, void* stream);
+int rvit_channel_scale_nhwc(void* x, const void* gate, int B, int HW, int C, void* stream);
 
 /* Fused stem entry for inference: conv 7x7/2 pad 3 (3->64) + folded BatchNorm (scale, bias) + ReLU +
  * max-pool 3x3/2 pad 1 in one kernel; the 112x112x64 map never reaches HBM.  Replaces timm resnet

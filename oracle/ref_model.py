@@ -70,9 +70,104 @@ class ResNetFeatures(nn.Module):
         return [f0, f1, f2, f3, f4]
 
 
+class _SqueezeExciteRef(nn.Module):
+    """timm SqueezeExcite as mobilenetv3 configures it: mean over H, W -> 1x1 conv (bias) -> ReLU -> 1x1 conv (bias) ->
+    hard-sigmoid gate (relu6(x + 3) / 6) -> multiply."""
+
+    def __init__(self, c: int, rd: int):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(c, rd, 1, bias=True)
+        self.conv_expand = nn.Conv2d(rd, c, 1, bias=True)
+
+    def forward(self, x):
+        g = self.conv_expand(torch.relu(self.conv_reduce(x.mean((2, 3), keepdim=True))))
+        return x * (nn.functional.relu6(g + 3.0) / 6.0)
+
+
+class _MbBlockRef(nn.Module):
+    def __init__(self, kind, cin, k, stride, mid, cout, se_rd, act):
+        super().__init__()
+        self.kind = kind
+        self.act = nn.ReLU() if act == "relu" else nn.Hardswish()
+        self.has_residual = kind != "cn" and stride == 1 and cin == cout
+        if kind == "ds":
+            self.conv_dw = nn.Conv2d(cin, cin, k, stride, k // 2, groups=cin, bias=False)
+            self.bn1 = nn.BatchNorm2d(cin)
+            self.se = _SqueezeExciteRef(cin, se_rd) if se_rd else None
+            self.conv_pw = nn.Conv2d(cin, cout, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(cout)
+        elif kind == "ir":
+            self.conv_pw = nn.Conv2d(cin, mid, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(mid)
+            self.conv_dw = nn.Conv2d(mid, mid, k, stride, k // 2, groups=mid, bias=False)
+            self.bn2 = nn.BatchNorm2d(mid)
+            self.se = _SqueezeExciteRef(mid, se_rd) if se_rd else None
+            self.conv_pwl = nn.Conv2d(mid, cout, 1, bias=False)
+            self.bn3 = nn.BatchNorm2d(cout)
+        else:
+            self.conv = nn.Conv2d(cin, cout, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(cout)
+        if kind != "cn" and not se_rd:
+            del self.se   # timm registers nn.Identity there: no keys either way
+
+    def forward(self, x):
+        if self.kind == "cn":
+            return self.act(self.bn1(self.conv(x)))
+        y = x
+        if self.kind == "ir":
+            y = self.act(self.bn1(self.conv_pw(y)))
+            y = self.act(self.bn2(self.conv_dw(y)))
+        else:
+            y = self.act(self.bn1(self.conv_dw(y)))
+        if hasattr(self, "se"):
+            y = self.se(y)
+        y = self.bn3(self.conv_pwl(y)) if self.kind == "ir" else self.bn2(self.conv_pw(y))
+        return x + y if self.has_residual else y
+
+
+class MobileNetV3SmallFeatures(nn.Module):
+    """timm `mobilenetv3_small_100`, `features_only=True` (train_vit.py:69,87), restated from the published
+    architecture (Howard et al. 2019, table 2) under timm's key names (conv_stem, bn1, blocks.<stage>.<i>.*).  timm is
+    not installed here and the reference ships no checkpoint of it: PARITY UNPINNED at this boundary, as for the
+    resnet stems; what pins the restatement is the published parameter count: this trunk (927,008) + timm's conv_head
+    (576 -> 1024 with bias, 590,848) + classifier (1024 -> 1000, 1,025,000) = 2,542,856 = the 2.54 M of mobilenetv3_small_100
+    (tests/test_oracle.py).  forward returns the feature maps at strides 2, 4, 8, 16, 32 (16, 16, 24, 48, 576 channels)."""
+    STAGES = (
+        (("ds", 3, 2, 16, 16, 8, "relu"),),
+        (("ir", 3, 2, 72, 24, 0, "relu"), ("ir", 3, 1, 88, 24, 0, "relu")),
+        (("ir", 5, 2, 96, 40, 24, "hswish"), ("ir", 5, 1, 240, 40, 64, "hswish"), ("ir", 5, 1, 240, 40, 64, "hswish")),
+        (("ir", 5, 1, 120, 48, 32, "hswish"), ("ir", 5, 1, 144, 48, 40, "hswish")),
+        (("ir", 5, 2, 288, 96, 72, "hswish"), ("ir", 5, 1, 576, 96, 144, "hswish"), ("ir", 5, 1, 576, 96, 144, "hswish")),
+        (("cn", 1, 1, 0, 576, 0, "hswish"),),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.conv_stem = nn.Conv2d(3, 16, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(16)
+        cin = 16
+        stages = []
+        for st in self.STAGES:
+            blks = []
+            for kind, k, stride, mid, cout, se_rd, act in st:
+                blks.append(_MbBlockRef(kind, cin, k, stride, mid, cout, se_rd, act))
+                cin = cout
+            stages.append(nn.Sequential(*blks))
+        self.blocks = nn.Sequential(*stages)
+
+    def forward(self, x):
+        x = nn.functional.hardswish(self.bn1(self.conv_stem(x)))
+        feats = [x]                       # stride 2
+        for i, st in enumerate(self.blocks):
+            x = st(x)
+            if i in (0, 1, 3, 5):         # last stage of strides 4, 8, 16, 32
+                feats.append(x)
+        return feats
+
+
 class CNNViTHybridRef(nn.Module):
     """train_vit.py:54-185 with the timm stem replaced by ResNetFeatures (or a 16x16 patch conv)."""
-    BACKBONES = {"resnet18": (512, 7), "resnet34": (512, 7), "patch16": (3, 14)}
+    BACKBONES = {"resnet18": (512, 7), "resnet34": (512, 7), "patch16": (3, 14), "mobilenetv3": (576, 7)}
 
     def __init__(self, num_classes, embed_dim=384, num_heads=6, num_layers=6, dropout=0.1, backbone="resnet18"):
         super().__init__()
@@ -85,7 +180,7 @@ class CNNViTHybridRef(nn.Module):
             self.cnn_backbone = None
             self.patch_embed = nn.Conv2d(3, embed_dim, kernel_size=16, stride=16)
         else:
-            self.cnn_backbone = ResNetFeatures(backbone)
+            self.cnn_backbone = MobileNetV3SmallFeatures() if backbone == "mobilenetv3" else ResNetFeatures(backbone)
             self.patch_embed = nn.Conv2d(cout, embed_dim, kernel_size=1)          # train_vit.py:93
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))               # :96
         self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, embed_dim))  # :99

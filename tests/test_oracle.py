@@ -185,3 +185,28 @@ def test_init_weights_semantics():
         assert torch.equal(s["norm.weight"], torch.ones(E)) and torch.count_nonzero(s["norm.bias"]) == 0
         pe = s["patch_embed.weight"]                               # nn.Conv2d default init, train_vit.py:93
         assert pe.abs().max().item() <= 1.0 / math.sqrt(512) + 1e-6
+
+
+def test_mobilenetv3_small_restatement_matches_the_published_size():
+    """oracle MobileNetV3SmallFeatures = timm mobilenetv3_small_100 features_only (train_vit.py:69,87) restated without
+    timm: the trunk's parameter count plus timm's conv_head (576 -> 1024, bias) and classifier (1024 -> 1000) must give
+    the published 2.54 M of mobilenetv3_small_100; feature maps at strides 2..32 have 16, 16, 24, 48, 576 channels (576
+    at 7x7 is what train_vit.py:69 declares); product and oracle state_dicts have the same keys and shapes."""
+    from oracle.ref_model import CNNViTHybridRef, MobileNetV3SmallFeatures
+    from vit_amd.model import CNNViTHybrid
+    f = MobileNetV3SmallFeatures().eval()
+    trunk = sum(p.numel() for p in f.parameters())
+    assert trunk == 927_008
+    assert trunk + (576 * 1024 + 1024) + (1024 * 1000 + 1000) == 2_542_856
+    with torch.no_grad():
+        shapes = [tuple(t.shape[1:]) for t in f(torch.zeros(1, 3, 224, 224))]
+    assert shapes == [(16, 112, 112), (16, 56, 56), (24, 28, 28), (48, 14, 14), (576, 7, 7)]
+    cfg = dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=1, backbone="mobilenetv3")
+    a = {k: tuple(v.shape) for k, v in CNNViTHybridRef(**cfg).state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in CNNViTHybrid(**cfg).state_dict().items()}
+    assert a == b
+    keys = set(a)
+    assert {"cnn_backbone.conv_stem.weight", "cnn_backbone.blocks.0.0.conv_dw.weight", "cnn_backbone.blocks.0.0.se.conv_reduce.bias",
+            "cnn_backbone.blocks.1.0.conv_pwl.weight", "cnn_backbone.blocks.4.2.bn3.running_var",
+            "cnn_backbone.blocks.5.0.conv.weight"} <= keys
+    assert "cnn_backbone.blocks.1.0.se.conv_reduce.weight" not in keys      # stage 1 has no squeeze-excite

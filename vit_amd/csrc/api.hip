@@ -53,7 +53,7 @@ int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra,
   a.drop_mode = drop_p > 0.f ? drop_mode : 0;
   a.drop = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(c_dtype == RVIT_BF16 || c_dtype == RVIT_F32, "gemm: bad c_dtype %d", c_dtype);
-  RVIT_CHECK_ARG(act >= 0 && act <= 2, "gemm: bad act %d", act);
+  RVIT_CHECK_ARG(act >= 0 && act <= RVIT_ACT_HSIGMOID, "gemm: bad act %d", act);
   RVIT_CHECK_ARG(!gate || gate_mode == RVIT_GATE_GELU_GRAD || gate_mode == RVIT_GATE_RELU_MASK, "gemm: bad gate mode");
   RVIT_CHECK_ARG(ldc >= N && (!R || ldr >= N) && (!preact || ldp >= N), "gemm: output pitch smaller than N");
   RVIT_CHECK_ARG(row_group >= 0 && row_extra >= 0 && r_period >= 0 && a_row_group >= 0 && a_row_extra >= 0,
@@ -104,7 +104,7 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
   a.scale = scale; a.bias = bias;
   a.R = residual; a.ldr = Cout; a.r_f32 = 0; a.r_period = 0;
   a.act = act; a.tile = tile;
-  RVIT_CHECK_ARG(act >= 0 && act <= 2, "conv: bad act %d", act);
+  RVIT_CHECK_ARG(act >= 0 && act <= RVIT_ACT_HSIGMOID, "conv: bad act %d", act);
   bool vec = (Cout & 7) == 0 && aligned_to(y, 16);
   if (scale) vec = vec && aligned_to(scale, 16);
   if (bias) vec = vec && aligned_to(bias, 16);
@@ -318,6 +318,17 @@ int rvit_attn_fwd_fp8(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out
 int rvit_attn_fwd_s64(const void* qkv, void* out, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
                       void* stream) {
   return rvit_attn16_impl(qkv, out, B, S, H, ldq, ldo, scale, (hipStream_t)stream);
+}
+
+int rvit_dwconv_fwd_bf16(const void* x, const void* w, const float* scale, const float* bias, void* out, int B, int H,
+                         int W, int C, int K, int stride, int pad, int act, void* stream) {
+  return rvit_dwconv_impl(x, w, scale, bias, out, B, H, W, C, K, stride, pad, act, (hipStream_t)stream);
+}
+int rvit_avgpool_nhwc(const void* x, void* out, int B, int HW, int C, void* stream) {
+  return rvit_avgpool_impl(x, out, B, HW, C, (hipStream_t)stream);
+}
+int rvit_channel_scale_nhwc(void* x, const void* gate, int B, int HW, int C, void* stream) {
+  return rvit_channel_scale_impl(x, gate, B, HW, C, (hipStream_t)stream);
 }
 
 int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,

@@ -138,6 +138,15 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
+// Activation codes of include/rvit.h on one fp32 value (the kernels that take `act` as a runtime argument)
+__device__ __forceinline__ float rvit_apply_act(float x, int act) {
+  if (act == RVIT_ACT_RELU) return fmaxf(x, 0.f);
+  if (act == RVIT_ACT_GELU) return gelu_erf(x);
+  if (act == RVIT_ACT_HSWISH) return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.0f / 6.0f);
+  if (act == RVIT_ACT_HSIGMOID) return fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.0f / 6.0f);
+  return x;
+}
+
 // Counter-based dropout (nn.Dropout of train_vit.py:100,107,125 and the attention-probability
 // dropout of torch functional.py:6569-6570).  Element `idx` of a dropout site keyed by (k0, k1) is
 // kept iff the top 24 bits of a two-round integer hash reach the threshold; forward and backward

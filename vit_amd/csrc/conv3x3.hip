@@ -405,7 +405,7 @@ bool rvit_conv3x3_direct_ok(const GemmArgs& a) {
   if (a.mode != 1 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.seg_len != a.Cpix) return false;
   if (a.K != 9 * a.Cpix || (a.Cpix & 63) != 0 || (a.N & 63) != 0 || a.H != a.Ho || a.W != a.Wo) return false;
   if (!a.vec || a.gate || a.C2 || a.drop_mode || a.c_f32 || a.r_f32 || a.r_period || a.row_group) return false;
-  if (a.act == RVIT_ACT_GELU || (a.R && a.ldr != a.N) || a.ldc != a.N || a.ldb != a.K) return false;
+  if ((a.act != RVIT_ACT_NONE && a.act != RVIT_ACT_RELU) || (a.R && a.ldr != a.N) || a.ldc != a.N || a.ldb != a.K) return false;
   const int P = c3_patch_pixels(a.H, a.W);
   if (P > C3_PMAX) return false;                        // DMA pass budget
   if (a.M % ((long)a.H * a.W) != 0 || a.M >= 0x7fffffffL) return false;

@@ -61,6 +61,9 @@ __device__ __forceinline__ void rvit_gemm_epilogue_row8(const GemmArgs& p, float
     } else if (p.act == RVIT_ACT_GELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    } else if (p.act >= RVIT_ACT_HSWISH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = rvit_apply_act(v[e], p.act);
     }
     if (p.drop_mode == RVIT_DROP_POST_ACT) {
       const uint32_t di = (uint32_t)(orow * p.N + n);
@@ -92,8 +95,7 @@ __device__ __forceinline__ void rvit_gemm_epilogue_row8(const GemmArgs& p, float
       if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) x *= drop_mult(p.drop, (uint32_t)(orow * p.N + n + e));
       if (p.R) x += p.r_f32 ? ((const float*)p.R)[rrow * p.ldr + n + e]
                             : (float)((const bf16*)p.R)[rrow * p.ldr + n + e];
-      if (p.act == RVIT_ACT_RELU) x = fmaxf(x, 0.f);
-      else if (p.act == RVIT_ACT_GELU) x = gelu_erf(x);
+      x = rvit_apply_act(x, p.act);
       if (p.drop_mode == RVIT_DROP_POST_ACT) x *= drop_mult(p.drop, (uint32_t)(orow * p.N + n + e));
       if (p.c_f32) ((float*)p.C)[orow * p.ldc + n + e] = x;
       else ((bf16*)p.C)[orow * p.ldc + n + e] = (bf16)x;

@@ -150,6 +150,10 @@ int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int
                        float drop_p, uint64_t drop_seed, hipStream_t st);
 int rvit_attn_fwd_fp8_impl(const void* qkv, uint8_t* out_q, long ldo, uint8_t* out_s, int B, int S, int H, long ldq,
                            float scale, hipStream_t st);
+int rvit_dwconv_impl(const void* x, const void* w, const float* scale, const float* bias, void* out, int B, int H, int W,
+                     int C, int K, int stride, int pad, int act, hipStream_t st);
+int rvit_avgpool_impl(const void* x, void* out, int B, int HW, int C, hipStream_t st);
+int rvit_channel_scale_impl(void* x, const void* gate, int B, int HW, int C, hipStream_t st);
 int rvit_attn16_impl(const void* qkv, void* out, int B, int S, int H, long ldq, long ldo, float scale, hipStream_t st);
 int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
                        long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,

@@ -85,7 +85,10 @@ class Engine:
         if dev.type != "cuda":
             raise RuntimeError("model parameters must be on a cuda device (no CPU path exists)")
         P: dict = {"device": dev}
-        if m.cnn_backbone is not None:
+        if m.backbone_name == "mobilenetv3":
+            P["mb"] = self._pack_mobilenet(m.cnn_backbone)
+            P["pe_w"] = m.patch_embed.weight.detach().reshape(m.embed_dim, -1).to(BF16).contiguous()
+        elif m.cnn_backbone is not None:
             cb = m.cnn_backbone
             s, b = _bn_fold(cb.bn1)
             w1 = _pack_conv_px4(cb.conv1.weight, 8)                       # [64, 7*32]
@@ -138,6 +141,95 @@ class Engine:
         self._pack, self._pack_key = P, key
         return P
 
+    @staticmethod
+    def _pack_mobilenet(cb) -> dict:
+        """Folded-BatchNorm weights of the mobilenetv3_small_100 stem: pointwise convs [Cout,Cin] bf16 (GEMM B operands),
+        depthwise convs [k*k, C] bf16 (tap-major), squeeze-excite projections as Linear weights with fp32 biases."""
+        def pw(conv, bn):
+            s, b = _bn_fold(bn)
+            return dict(w=conv.weight.detach().reshape(conv.weight.shape[0], -1).to(BF16).contiguous(), scale=s, bias=b)
+
+        def dw(conv, bn):
+            s, b = _bn_fold(bn)
+            c, k = conv.c, conv.k
+            return dict(w=conv.weight.detach().reshape(c, k * k).t().to(BF16).contiguous(), scale=s, bias=b, k=k,
+                        stride=conv.stride, pad=conv.pad)
+
+        def se(mod):
+            return dict(w1=mod.conv_reduce.weight.detach().reshape(mod.conv_reduce.weight.shape[0], -1).to(BF16).contiguous(),
+                        b1=mod.conv_reduce.bias.detach().float().contiguous(),
+                        w2=mod.conv_expand.weight.detach().reshape(mod.conv_expand.weight.shape[0], -1).to(BF16).contiguous(),
+                        b2=mod.conv_expand.bias.detach().float().contiguous())
+        s, b = _bn_fold(cb.bn1)
+        # 3x3 / stride 2 stem conv over the NHWC4 image: a kernel row is 4 pixels x 4 channels = 16 elements (3 taps used)
+        out = dict(stem=dict(w=_pack_conv_px4(cb.conv_stem.weight, 4), scale=s, bias=b), blocks=[])
+        for blk in cb.all_blocks():
+            d = dict(kind=blk.kind, act=blk.act, cin=blk.cin, cout=blk.cout, mid=blk.mid, stride=blk.stride,
+                     residual=blk.has_residual, se=se(blk.se) if hasattr(blk, "se") else None)
+            if blk.kind == "ds":
+                d["dw"], d["pwl"] = dw(blk.conv_dw, blk.bn1), pw(blk.conv_pw, blk.bn2)
+            elif blk.kind == "ir":
+                d["pw"], d["dw"], d["pwl"] = pw(blk.conv_pw, blk.bn1), dw(blk.conv_dw, blk.bn2), pw(blk.conv_pwl, blk.bn3)
+            else:
+                d["pw"] = pw(blk.conv, blk.bn1)
+            out["blocks"].append(d)
+        return out
+
+    def _stem_mobilenet(self, P, b, B, xin) -> torch.Tensor:
+        """mobilenetv3_small_100 features_only, last map [B,7,7,576] (NHWC bf16).  conv_stem is an implicit GEMM over the
+        zero-haloed NHWC4 image; every pointwise conv and squeeze-excite projection is a GEMM over the NHWC map viewed
+        as [B*H*W, C] with the folded BatchNorm, activation and residual in its epilogue; depthwise convs, the
+        squeeze-excite pool and the gate multiply are the HBM-bound kernels of csrc/mobile.hip."""
+        mb = P["mb"]
+        dev = xin.device
+        z = dict(dtype=BF16, device=dev)
+        cache = b.setdefault("mb_maps", {})
+
+        def buf(key, *shape):
+            t = cache.get(key)
+            if t is None or tuple(t.shape) != shape:
+                t = torch.empty(*shape, **z)
+                cache[key] = t
+            return t
+        ops.input_pack(xin, b["img"], 1, 1)
+        st = mb["stem"]
+        cur = buf("stem", B, 112, 112, 16)
+        ops.conv2d(b["img"], st["w"], cur, kh=3, kw=1, stride=2, pad=0, seg_len=16, scale=st["scale"], bias=st["bias"],
+                   act="hswish")
+        for i, d in enumerate(mb["blocks"]):
+            Bc, H, W, C = cur.shape
+            x_in = cur
+            if d["kind"] == "cn":
+                p = d["pw"]
+                out = buf(f"o{i}", Bc, H, W, d["cout"])
+                ops.gemm(cur.view(-1, C), p["w"], out.view(-1, d["cout"]), scale=p["scale"], bias=p["bias"], act=d["act"])
+                cur = out
+                continue
+            if d["kind"] == "ir":
+                p = d["pw"]
+                mid = buf(f"m{i}", Bc, H, W, d["mid"])
+                ops.gemm(cur.view(-1, C), p["w"], mid.view(-1, d["mid"]), scale=p["scale"], bias=p["bias"], act=d["act"])
+                cur = mid
+            q = d["dw"]
+            Cm = cur.shape[3]
+            Ho, Wo = (H + 2 * q["pad"] - q["k"]) // q["stride"] + 1, (W + 2 * q["pad"] - q["k"]) // q["stride"] + 1
+            dwo = buf(f"d{i}", Bc, Ho, Wo, Cm)
+            ops.dwconv(cur, q["w"], q["scale"], q["bias"], dwo, k=q["k"], stride=q["stride"], pad=q["pad"], act=d["act"])
+            if d["se"] is not None:
+                s_ = d["se"]
+                rd = s_["w1"].shape[0]
+                pooled, hid, gate = buf(f"sp{i}", Bc, Cm), buf(f"sh{i}", Bc, rd), buf(f"sg{i}", Bc, Cm)
+                ops.avgpool(dwo, pooled)
+                ops.gemm(pooled, s_["w1"], hid, bias=s_["b1"], act="relu")
+                ops.gemm(hid, s_["w2"], gate, bias=s_["b2"], act="hsigmoid")
+                ops.channel_scale(dwo, gate)
+            p = d["pwl"]
+            out = buf(f"o{i}", Bc, Ho, Wo, d["cout"])
+            ops.gemm(dwo.view(-1, Cm), p["w"], out.view(-1, d["cout"]), scale=p["scale"], bias=p["bias"],
+                     residual=x_in.view(-1, d["cout"]) if d["residual"] else None)
+            cur = out
+        return cur
+
     # ---- activation buffers ------------------------------------------------------------------
     def buffers(self, B: int, dev) -> Dict[str, torch.Tensor]:
         bufs = self._bufs.get(B)
@@ -150,7 +242,9 @@ class Engine:
         T = B * S
         z = dict(dtype=BF16, device=dev)
         b: Dict[str, torch.Tensor] = {}
-        if m.cnn_backbone is not None:
+        if m.backbone_name == "mobilenetv3":
+            b["img"] = torch.zeros(B, 226, 228, 4, **z)  # halo 1 top / left, 1 / 3 bottom / right; stays zero
+        elif m.cnn_backbone is not None:
             b["img"] = torch.zeros(B, 230, 232, 4, **z)  # halo stays zero forever
             hw = 56
             for li, c in enumerate((64, 128, 256, 512), start=1):
@@ -267,7 +361,7 @@ class Engine:
         xs = b["x"]
         x2 = xs.view(T, E)
         if m.cnn_backbone is not None:
-            feat = self._stem(P, b, B, xin)  # [B,7,7,512]
+            feat = self._stem_mobilenet(P, b, B, xin) if m.backbone_name == "mobilenetv3" else self._stem(P, b, B, xin)  # [B,7,7,C]
             ops.gemm(feat.view(B * m.num_patches, -1), P["pe_w"], x2, bias=P["pe_b"], residual=P["pos"][1:],
                      residual_period=m.num_patches, row_group=m.num_patches, row_extra=1)
         else:

@@ -98,6 +98,88 @@ class _ResNetStem(nn.Module):
                 yield blk
 
 
+class _SqueezeExcite(nn.Module):
+    """timm SqueezeExcite parameter names: 1x1 convs WITH bias."""
+
+    def __init__(self, c: int, rd: int):
+        super().__init__()
+        self.conv_reduce = _Conv(c, rd, 1, 1, 0, bias=True)
+        self.conv_expand = _Conv(rd, c, 1, 1, 0, bias=True)
+
+
+class _DwConv(nn.Module):
+    """Depthwise conv holder named like nn.Conv2d(groups=C): weight [C,1,k,k]."""
+
+    def __init__(self, c: int, k: int, stride: int):
+        super().__init__()
+        self.c, self.k, self.stride, self.pad = c, k, stride, k // 2
+        self.weight = nn.Parameter(torch.empty(c, 1, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+
+
+class _MbBlock(nn.Module):
+    """One block of timm mobilenetv3_small_100 under timm's key names.
+    kind 'ds' (DepthwiseSeparableConv): conv_dw, bn1, [se], conv_pw, bn2
+    kind 'ir' (InvertedResidual):       conv_pw, bn1, conv_dw, bn2, [se], conv_pwl, bn3
+    kind 'cn' (ConvBnAct):              conv, bn1"""
+
+    def __init__(self, kind, cin, k, stride, mid, cout, se_rd, act):
+        super().__init__()
+        self.kind, self.cin, self.k, self.stride, self.mid, self.cout, self.act = kind, cin, k, stride, mid, cout, act
+        self.has_residual = kind != "cn" and stride == 1 and cin == cout
+        if kind == "ds":
+            self.conv_dw, self.bn1 = _DwConv(cin, k, stride), _BatchNorm(cin)
+            if se_rd:
+                self.se = _SqueezeExcite(cin, se_rd)
+            self.conv_pw, self.bn2 = _Conv(cin, cout, 1, 1, 0), _BatchNorm(cout)
+        elif kind == "ir":
+            self.conv_pw, self.bn1 = _Conv(cin, mid, 1, 1, 0), _BatchNorm(mid)
+            self.conv_dw, self.bn2 = _DwConv(mid, k, stride), _BatchNorm(mid)
+            if se_rd:
+                self.se = _SqueezeExcite(mid, se_rd)
+            self.conv_pwl, self.bn3 = _Conv(mid, cout, 1, 1, 0), _BatchNorm(cout)
+        else:
+            self.conv, self.bn1 = _Conv(cin, cout, 1, 1, 0), _BatchNorm(cout)
+
+
+class _MobileNetV3SmallStem(nn.Module):
+    """timm `mobilenetv3_small_100` with `features_only=True` (train_vit.py:69,87): conv_stem / bn1 and six stages
+    `blocks.<stage>.<index>`; the last feature map, [B,576,7,7], is what the classifier consumes (train_vit.py:145-146).
+    Architecture (Howard et al. 2019, table 2; timm's arch_def ds_r1_k3_s2_e1_c16_se0.25_nre / ir_r1_k3_s2_e4.5_c24_nre,
+    ir_r1_k3_s1_e3.67_c24_nre / ir_r1_k5_s2_e4_c40_se0.25, ir_r2_k5_s1_e6_c40_se0.25 / ir_r2_k5_s1_e3_c48_se0.25 /
+    ir_r3_k5_s2_e6_c96_se0.25 / cn_r1_k1_s1_c576; squeeze-excite widths from the expanded width x 0.25 rounded to 8,
+    ReLU inside, hard-sigmoid gate; hard-swish from stage 2 on).  timm is not installed here: parity of this stem is
+    unpinned in the same sense as the resnet stems' (DESIGN.md section 3)."""
+    # (kind, k, stride, mid, cout, se_rd, act)
+    STAGES = (
+        (("ds", 3, 2, 16, 16, 8, "relu"),),
+        (("ir", 3, 2, 72, 24, 0, "relu"), ("ir", 3, 1, 88, 24, 0, "relu")),
+        (("ir", 5, 2, 96, 40, 24, "hswish"), ("ir", 5, 1, 240, 40, 64, "hswish"), ("ir", 5, 1, 240, 40, 64, "hswish")),
+        (("ir", 5, 1, 120, 48, 32, "hswish"), ("ir", 5, 1, 144, 48, 40, "hswish")),
+        (("ir", 5, 2, 288, 96, 72, "hswish"), ("ir", 5, 1, 576, 96, 144, "hswish"), ("ir", 5, 1, 576, 96, 144, "hswish")),
+        (("cn", 1, 1, 0, 576, 0, "hswish"),),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.conv_stem = _Conv(3, 16, 3, 2, 1)
+        self.bn1 = _BatchNorm(16)
+        cin = 16
+        stages = []
+        for st in self.STAGES:
+            blks = []
+            for kind, k, stride, mid, cout, se_rd, act in st:
+                blks.append(_MbBlock(kind, cin, k, stride, mid, cout, se_rd, act))
+                cin = cout
+            stages.append(nn.ModuleList(blks))
+        self.blocks = nn.ModuleList(stages)
+
+    def all_blocks(self):
+        for st in self.blocks:
+            for blk in st:
+                yield blk
+
+
 class _SelfAttn(nn.Module):
     """nn.MultiheadAttention parameter names and default init (torch activation.py _reset_parameters)."""
 
@@ -150,7 +232,8 @@ class CNNViTHybrid(nn.Module):
         "efficientnet_b2": ("efficientnet_b2", 1408, 7),
         "patch16": ("patch16", 3, 14),
     }
-    _HIP_STEMS = ("resnet18", "resnet34", "patch16")
+    _HIP_STEMS = ("resnet18", "resnet34", "patch16", "mobilenetv3")
+    _TRAIN_STEMS = ("resnet18", "resnet34", "patch16")   # the mobilenetv3 stem is built for inference only
 
     def __init__(self, num_classes, embed_dim=384, num_heads=6, num_layers=6, dropout=0.1,
                  pretrained_backbone=False, backbone="resnet34"):
@@ -159,6 +242,9 @@ class CNNViTHybrid(nn.Module):
         if backbone not in self.BACKBONES:
             raise ValueError(f"Unknown backbone: {backbone}. Choose from {list(self.BACKBONES.keys())}")
         if backbone not in self._HIP_STEMS:
+            # efficientnet_b0/b2: besides being unbuilt, the reference's own table is inconsistent for them: timm's
+            # features_only efficientnet returns 320 / 352 channels at stride 32, not the 1280 / 1408 of its classifier
+            # head that train_vit.py:72-73 feeds to patch_embed
             raise NotImplementedError(f"backbone {backbone!r}: no HIP stem yet (out of scope, SURVEY.md §8f #4)")
         if embed_dim % num_heads != 0 or embed_dim // num_heads != 64:
             raise NotImplementedError("HIP attention kernel supports head_dim 64 only "
@@ -171,7 +257,7 @@ class CNNViTHybrid(nn.Module):
             self.cnn_backbone = None
             self.patch_embed = _Conv(3, embed_dim, 16, 16, 0, bias=True)
         else:
-            self.cnn_backbone = _ResNetStem(backbone)
+            self.cnn_backbone = _MobileNetV3SmallStem() if backbone == "mobilenetv3" else _ResNetStem(backbone)
             self.patch_embed = _Conv(cnn_out, embed_dim, 1, 1, 0, bias=True)
         # nn.Conv2d default init for patch_embed (reference keeps torch defaults, train_vit.py:93)
         nn.init.kaiming_uniform_(self.patch_embed.weight, a=math.sqrt(5))
@@ -293,6 +379,9 @@ class CNNViTHybrid(nn.Module):
             return self._run_on_device(x, features_only)
 
     def _run_on_device(self, x, features_only: bool):
+        if self.training and self.backbone_name not in self._TRAIN_STEMS:
+            raise NotImplementedError(f"backbone {self.backbone_name!r} is built for inference: call .eval() "
+                                      "(training kernels exist for the resnet stems and patch16)")
         if self.training:
             # train(): BatchNorm batch statistics; backward on librvit when gradients are recorded.
             # A training forward means the weights are about to change: the inference engine re-packs next time

@@ -14,7 +14,8 @@ from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, GATE_GELU_GRAD, GATE_RELU_MASK, RVIT_BF16, RVIT_F32,  # noqa: F401
                    check)
 
-_ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
+_ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU, "hswish": _lib.ACT_HSWISH,
+        "hsigmoid": _lib.ACT_HSIGMOID}
 _GATE = {None: 0, "gelu_grad": GATE_GELU_GRAD, "relu_mask": GATE_RELU_MASK}
 BF16 = torch.bfloat16
 
@@ -540,6 +541,46 @@ def encoder_attn_supported(E: int, H: int, S: int) -> bool:
 
 def encoder_mlp_supported(E: int, hidden: int) -> bool:
     return E == 256 and hidden > 0 and hidden % 256 == 0
+
+
+def dwconv(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, *, k: int,
+           stride: int, pad: int, act: Optional[str] = None) -> torch.Tensor:
+    """Depthwise k x k conv + per-channel scale/bias + activation; x bf16 NHWC [B,H,W,C], w bf16 [k*k, C]."""
+    _need_cuda(x, w, scale, bias, out)
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if x.dtype != BF16 or out.dtype != BF16 or w.dtype != BF16 or not (x.is_contiguous() and out.is_contiguous() and w.is_contiguous()) \
+            or tuple(w.shape) != (k * k, C) or tuple(out.shape) != (B, Ho, Wo, C) or C % 8:
+        raise ValueError(f"dwconv: x {tuple(x.shape)} / w {tuple(w.shape)} / out {tuple(out.shape)} mismatch (bf16, C % 8 == 0)")
+    _vec_f32(scale, C, "dwconv: scale")
+    _vec_f32(bias, C, "dwconv: bias")
+    with _Span("dwconv", 2 * B * Ho * Wo * C * k * k, _nbytes(x, out)):
+        check(_lib.load().rvit_dwconv_fwd_bf16(x.data_ptr(), w.data_ptr(), scale.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                               B, H, W, C, k, stride, pad, _ACT[act], _stream()), "rvit_dwconv_fwd_bf16")
+    return out
+
+
+def avgpool(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[b, c] = mean over the pixels of x [B,H,W,C] (bf16 in, bf16 [B,C] out)."""
+    _need_cuda(x, out)
+    B, H, W, C = x.shape
+    if x.dtype != BF16 or out.dtype != BF16 or not x.is_contiguous() or not out.is_contiguous() or tuple(out.shape) != (B, C):
+        raise ValueError("avgpool: x bf16 [B,H,W,C] contiguous, out bf16 [B,C]")
+    with _Span("avgpool", 0, _nbytes(x, out)):
+        check(_lib.load().rvit_avgpool_nhwc(x.data_ptr(), out.data_ptr(), B, H * W, C, _stream()), "rvit_avgpool_nhwc")
+    return out
+
+
+def channel_scale(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """x[b, h, w, c] *= gate[b, c] in place (bf16)."""
+    _need_cuda(x, gate)
+    B, H, W, C = x.shape
+    if x.dtype != BF16 or gate.dtype != BF16 or not x.is_contiguous() or not gate.is_contiguous() or tuple(gate.shape) != (B, C):
+        raise ValueError("channel_scale: x bf16 [B,H,W,C] contiguous, gate bf16 [B,C]")
+    with _Span("channel_scale", 0, 2 * _nbytes(x)):
+        check(_lib.load().rvit_channel_scale_nhwc(x.data_ptr(), gate.data_ptr(), B, H * W, C, _stream()),
+              "rvit_channel_scale_nhwc")
+    return x
 
 
 def attention_s64(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, scale: Optional[float] = None) -> torch.Tensor:
