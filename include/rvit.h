@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 16
+#define RVIT_ABI_VERSION 17
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -181,11 +181,32 @@ int rvit_conv2d_wgrad_bf16(const void* dy, const void* x, float* dW, int B, int 
  *   rvit_dwconv_fwd_bf16: depthwise K x K (K 3 or 5, stride 1 or 2) + folded BatchNorm (scale, bias) + activation;
  *     w: bf16 [K*K, C] (tap-major); out [B, Ho, Wo, C].
  *   rvit_avgpool_nhwc: out[b, c] = mean over the HW pixels (bf16 [B, C]).
- *   rvit_channel_scale_nhwc: x[b, p, c] *= gate[b, c] in place (bf16 gate [B, C]). */
+ *   rvit_channel_scale_nhwc: x[b, p, c] *= gate[b, c] in place (bf16 gate [B, C]).
+ *   rvit_squeeze_excite_bf16: the whole squeeze-excite block (timm SqueezeExcite: mean over HW, conv_reduce + ReLU,
+ *     conv_expand + hard-sigmoid, multiply) in one launch and in place, one image's map resident in LDS: x [B, HW, C],
+ *     w1 bf16 [RD, C], b1 f32 [RD], w2 bf16 [C, RD], b2 f32 [C]; RD % 8 == 0.  Rejects maps whose LDS need
+ *     (2*HW*C + 4*(512/(C/8)*C + 2*C + RD) bytes) exceeds RVIT_SE_MAX_LDS_BYTES: use the three calls above then.
+ *   rvit_pointwise_conv_bf16: 1x1 convolution + folded BatchNorm + residual + activation over the map viewed as
+ *     x [M, K] (M = B*H*W): out[m, n] = act(scale[n] * sum_k x[m, k] w[n, k] + bias[n] + residual[m, n]); w bf16 [N, K],
+ *     scale / bias / residual may be NULL.  For the small K and N of these stems (K, N % 8 == 0, K <= 256, the weights
+ *     as MFMA operands within RVIT_POINTWISE_MAX_LDS_BYTES: rvit_pointwise_conv_supported says); same result as
+ *     rvit_gemm_bf16 with the same epilogue up to summation order within one MFMA.
+ *   rvit_conv3x3s2_rgb_f32_fwd: conv_stem + bn1 + activation straight from the model's input: 3x3 / stride 2 / pad 1,
+ *     3 -> 16 channels, x_nchw f32 [B, 3, H, W] (H, W even), w f32 [27, 16] with k = (kh*3 + kw)*3 + ci,
+ *     out bf16 [B, H/2, W/2, 16]. */
+#define RVIT_SE_MAX_LDS_BYTES (160 * 1024)
+#define RVIT_POINTWISE_MAX_LDS_BYTES (64 * 1024)
 int rvit_dwconv_fwd_bf16(const void* x, const void* w, const float* scale, const float* bias, void* out, int B, int H,
                          int W, int C, int K, int stride, int pad, int act, void* stream);
 int rvit_avgpool_nhwc(const void* x, void* out, int B, int HW, int C, void* stream);
 int rvit_channel_scale_nhwc(void* x, const void* gate, int B, int HW, int C, void* stream);
+int rvit_squeeze_excite_bf16(void* x, const void* w1, const float* b1, const void* w2, const float* b2, int B, int HW, int C,
+                             int RD, void* stream);
+int rvit_pointwise_conv_bf16(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
+                             void* out, int64_t M, int K, int N, int act, void* stream);
+int rvit_pointwise_conv_supported(int K, int N);
+int rvit_conv3x3s2_rgb_f32_fwd(const float* x_nchw, const float* w, const float* scale, const float* bias, void* out, int B,
+                               int H, int W, int Cout, int act, void* stream);
 
 /* Fused stem entry for inference: conv 7x7/2 pad 3 (3->64) + folded BatchNorm (scale, bias) + ReLU +
  * max-pool 3x3/2 pad 1 in one kernel; the 112x112x64 map never reaches HBM.  Replaces timm resnet

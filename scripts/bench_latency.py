@@ -1,11 +1,12 @@
-"""Developer aid: forward latency / throughput of the R hybrid over batch sizes (BASELINE configs[1] sweep)."""
+"""Developer aid: forward latency / throughput of the R hybrid over batch sizes (BASELINE configs[1] sweep);
+RVIT_BACKBONE picks the stem (resnet18 | resnet34 | mobilenetv3 | none)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vit_amd.model import CNNViTHybrid
 from vit_amd.synth import synth_state_dict
 dev = torch.device("cuda:0")
-m = CNNViTHybrid(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18")
+m = CNNViTHybrid(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone=os.environ.get("RVIT_BACKBONE", "resnet18"))
 m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, 0))
 m = m.to(dev).eval()
 if os.environ.get("RVIT_GRAPHS"):

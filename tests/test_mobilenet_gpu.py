@@ -14,8 +14,11 @@ def _act(t, name):
     return {"relu": torch.relu, "hswish": F.hardswish, "hsigmoid": F.hardsigmoid, None: lambda u: u}[name](t)
 
 
+# Wo % 7 == 0 runs the strip kernel (7 outputs per thread), anything else the one-output-per-thread kernel
 @pytest.mark.parametrize("B,H,C,k,stride,act", [(3, 56, 16, 3, 2, "relu"), (2, 28, 96, 5, 2, "hswish"), (2, 14, 240, 5, 1, "hswish"),
-                                               (5, 7, 576, 5, 1, "hswish"), (1, 9, 8, 3, 1, None), (2, 15, 24, 5, 2, "relu")])
+                                               (5, 7, 576, 5, 1, "hswish"), (1, 9, 8, 3, 1, None), (2, 15, 24, 5, 2, "relu"),
+                                               (2, 112, 16, 3, 2, "relu"), (2, 28, 88, 3, 1, "relu"), (3, 21, 40, 5, 1, None),
+                                               (1, 14, 8, 3, 2, "hswish")])
 def test_dwconv_matches_torch(dev, B, H, C, k, stride, act):
     from vit_amd import ops
     g = torch.Generator().manual_seed(H * C + k)
@@ -54,6 +57,88 @@ def test_avgpool_channel_scale_and_new_gemm_activations(dev):
         ops.gemm(a.to(dev), w.to(dev), out, scale=scale.to(dev), bias=bias.to(dev), act=act)
         ref = _act((a.float() @ w.float().T) * scale + bias, act)
         assert (out.float().cpu() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,C,RD", [(3, 28, 16, 8), (5, 14, 240, 64), (2, 7, 576, 144), (4, 14, 96, 24), (1, 14, 120, 32)])
+def test_squeeze_excite_one_launch_matches_the_four_launch_form(dev, B, H, C, RD):
+    """Same rounding points (pooled mean, ReLU output, gate in bf16); the projections sum in a different order than the
+    MFMA GEMMs, so a gate may differ by one bf16 step and the product by one more rounding of it."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(C + RD)
+    x = torch.randn(B, H, H, C, generator=g).to(BF16)
+    w1, b1 = (torch.randn(RD, C, generator=g) * 0.2).to(BF16), torch.randn(RD, generator=g) * 0.1
+    w2, b2 = (torch.randn(C, RD, generator=g) * 0.3).to(BF16), torch.randn(C, generator=g) * 0.5
+    assert ops.squeeze_excite_supported(H * H, C, RD)
+    fused = x.to(dev).clone()
+    ops.squeeze_excite(fused, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev))
+    ref4 = x.to(dev).clone()
+    pooled, hid, gate = (torch.empty(B, n, dtype=BF16, device=dev) for n in (C, RD, C))
+    ops.avgpool(ref4, pooled)
+    ops.gemm(pooled, w1.to(dev), hid, bias=b1.to(dev), act="relu")
+    ops.gemm(hid, w2.to(dev), gate, bias=b2.to(dev), act="hsigmoid")
+    ops.channel_scale(ref4, gate)
+    xf = x.float()
+    p = xf.mean((1, 2)).to(BF16).float()
+    h = torch.relu(p @ w1.float().T + b1).to(BF16).float()
+    gt = F.hardsigmoid(h @ w2.float().T + b2).to(BF16).float()
+    want = xf * gt.view(B, 1, 1, C)
+    for got in (fused, ref4):
+        err = (got.float().cpu() - want).abs()
+        assert (err <= 2 ** -6 * xf.abs() + 1e-6).all(), err.max().item()   # gate off by <= 1 bf16 step + 1 rounding
+    assert (fused.float() - ref4.float()).abs().max().item() <= 2 ** -6 * xf.abs().max().item()
+    assert (fused == ref4).float().mean().item() >= 0.9
+    assert not ops.squeeze_excite_supported(56 * 56, 72, 24)      # 451 KB map: the engine falls back to four launches
+    big = torch.zeros(1, 56, 56, 72, dtype=BF16, device=dev)
+    with pytest.raises(Exception, match="LDS"):
+        ops.squeeze_excite(big, torch.zeros(24, 72, dtype=BF16, device=dev), torch.zeros(24, device=dev),
+                           torch.zeros(72, 24, dtype=BF16, device=dev), torch.zeros(72, device=dev))
+
+
+@pytest.mark.parametrize("B,H,W,act", [(3, 224, 224, "hswish"), (2, 32, 48, None), (1, 6, 4, "relu")])
+def test_conv3x3s2_rgb_matches_torch(dev, B, H, W, act):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(16, 3, 3, 3, generator=g) * 0.3
+    scale, bias = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.2
+    out = torch.empty(B, H // 2, W // 2, 16, dtype=BF16, device=dev)
+    ops.conv3x3s2_rgb(x.to(dev), w.permute(2, 3, 1, 0).reshape(27, 16).contiguous().to(dev), scale.to(dev), bias.to(dev), out, act=act)
+    ref = _act(F.conv2d(x, w, None, 2, 1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1), act).permute(0, 2, 3, 1)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= 2 ** -8 * max(1.0, ref.abs().max().item()) + 1e-5, err   # fp32 arithmetic, one bf16 rounding of the output
+
+
+@pytest.mark.parametrize("M,K,N,act,res", [(3 * 56 * 56, 16, 16, None, False), (2 * 56 * 56 + 5, 16, 72, "relu", False),
+                                            (28 * 28, 72, 24, None, False), (1000, 88, 24, None, True), (777, 24, 96, "hswish", False),
+                                            (14 * 14 * 3, 240, 40, None, True), (100, 40, 240, "hswish", False),
+                                            (49 * 4, 144, 48, None, True), (1, 48, 144, "hswish", False), (16, 120, 48, None, False),
+                                            (70000, 40, 120, "hswish", False)])
+def test_pointwise_conv_matches_torch_and_the_general_gemm(dev, M, K, N, act, res):
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M + K * N)
+    x = torch.randn(M, K, generator=g).to(BF16)
+    w = (torch.randn(N, K, generator=g) * 0.3).to(BF16)
+    scale, bias = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    r = torch.randn(M, N, generator=g).to(BF16) if res else None
+    assert ops.pointwise_supported(K, N)
+    out, out_g = (torch.full((M, N), 7.0, dtype=BF16, device=dev) for _ in range(2))
+    rd = r.to(dev) if res else None
+    ops.pointwise_conv(x.to(dev), w.to(dev), out, scale=scale.to(dev), bias=bias.to(dev), residual=rd, act=act)
+    ops.gemm(x.to(dev), w.to(dev), out_g, scale=scale.to(dev), bias=bias.to(dev), residual=rd, act=act)
+    ref = (x.float() @ w.float().T) * scale + bias
+    ref = _act(ref + r.float() if res else ref, act)
+    tol = 2 ** -7 * max(1.0, ref.abs().max().item())
+    assert (out.float().cpu() - ref).abs().max().item() <= tol
+    assert (out.float() - out_g.float()).abs().max().item() <= tol
+    assert (out == out_g).float().mean().item() >= 0.98    # same products, fp32 sums in a different order
+
+
+def test_pointwise_conv_refuses_what_it_cannot_hold(dev):
+    from vit_amd import ops
+    assert not ops.pointwise_supported(96, 576) and not ops.pointwise_supported(576, 96) and not ops.pointwise_supported(20, 16)
+    with pytest.raises(Exception, match="rvit_gemm_bf16"):
+        ops.pointwise_conv(torch.zeros(8, 576, dtype=BF16, device=dev), torch.zeros(96, 576, dtype=BF16, device=dev),
+                           torch.zeros(8, 96, dtype=BF16, device=dev))
 
 
 def _pair(dev, seed=7):

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 16
+ABI_VERSION = 17
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -62,6 +62,10 @@ SIGNATURES = {
     "rvit_dwconv_fwd_bf16": ([P, P, P, P, P, I, I, I, I, I, I, I, I, P], c_int),
     "rvit_avgpool_nhwc": ([P, P, I, I, I, P], c_int),
     "rvit_channel_scale_nhwc": ([P, P, I, I, I, P], c_int),
+    "rvit_squeeze_excite_bf16": ([P, P, P, P, P, I, I, I, I, P], c_int),
+    "rvit_pointwise_conv_bf16": ([P, P, P, P, P, P, L, I, I, I, P], c_int),
+    "rvit_pointwise_conv_supported": ([I, I], c_int),
+    "rvit_conv3x3s2_rgb_f32_fwd": ([P, P, P, P, P, I, I, I, I, I, P], c_int),
     "rvit_attn_fwd_s64": ([P, P, I, I, I, L, L, F, P], c_int),
     "rvit_attn_bwd": ([P, P, P, P, P, I, I, I, L, L, L, L, F, F, U64, P], c_int),
     "rvit_ce_loss": ([P, L, P, P, P, L, P, L, I, I, I, F, F, P], c_int),

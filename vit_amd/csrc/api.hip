@@ -330,6 +330,19 @@ int rvit_avgpool_nhwc(const void* x, void* out, int B, int HW, int C, void* stre
 int rvit_channel_scale_nhwc(void* x, const void* gate, int B, int HW, int C, void* stream) {
   return rvit_channel_scale_impl(x, gate, B, HW, C, (hipStream_t)stream);
 }
+int rvit_squeeze_excite_bf16(void* x, const void* w1, const float* b1, const void* w2, const float* b2, int B, int HW, int C,
+                             int RD, void* stream) {
+  return rvit_squeeze_excite_impl(x, w1, b1, w2, b2, B, HW, C, RD, (hipStream_t)stream);
+}
+int rvit_pointwise_conv_bf16(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
+                             void* out, int64_t M, int K, int N, int act, void* stream) {
+  return rvit_pointwise_impl(x, w, scale, bias, residual, out, (long)M, K, N, act, (hipStream_t)stream);
+}
+int rvit_pointwise_conv_supported(int K, int N) { return rvit_pointwise_lds_bytes(K, N) > 0 ? 1 : 0; }
+int rvit_conv3x3s2_rgb_f32_fwd(const float* x_nchw, const float* w, const float* scale, const float* bias, void* out, int B,
+                               int H, int W, int Cout, int act, void* stream) {
+  return rvit_conv3x3s2_rgb_impl(x_nchw, w, scale, bias, out, B, H, W, Cout, act, (hipStream_t)stream);
+}
 
 int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                        const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,

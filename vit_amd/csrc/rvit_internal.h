@@ -154,6 +154,13 @@ int rvit_dwconv_impl(const void* x, const void* w, const float* scale, const flo
                      int C, int K, int stride, int pad, int act, hipStream_t st);
 int rvit_avgpool_impl(const void* x, void* out, int B, int HW, int C, hipStream_t st);
 int rvit_channel_scale_impl(void* x, const void* gate, int B, int HW, int C, hipStream_t st);
+int rvit_squeeze_excite_impl(void* x, const void* w1, const float* b1, const void* w2, const float* b2, int B, int HW, int C,
+                             int RD, hipStream_t st);
+long rvit_pointwise_lds_bytes(int K, int N);
+int rvit_pointwise_impl(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* out,
+                        long M, int K, int N, int act, hipStream_t st);
+int rvit_conv3x3s2_rgb_impl(const float* x, const float* w, const float* scale, const float* bias, void* out, int B, int H,
+                            int W, int Cout, int act, hipStream_t st);
 int rvit_attn16_impl(const void* qkv, void* out, int B, int S, int H, long ldq, long ldo, float scale, hipStream_t st);
 int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
                        long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,

@@ -161,8 +161,9 @@ class Engine:
                         w2=mod.conv_expand.weight.detach().reshape(mod.conv_expand.weight.shape[0], -1).to(BF16).contiguous(),
                         b2=mod.conv_expand.bias.detach().float().contiguous())
         s, b = _bn_fold(cb.bn1)
-        # 3x3 / stride 2 stem conv over the NHWC4 image: a kernel row is 4 pixels x 4 channels = 16 elements (3 taps used)
-        out = dict(stem=dict(w=_pack_conv_px4(cb.conv_stem.weight, 4), scale=s, bias=b), blocks=[])
+        # 3x3 / stride 2 stem conv straight from the fp32 input: weights f32 [27, 16], k = (kh*3 + kw)*3 + ci
+        w27 = cb.conv_stem.weight.detach().float().permute(2, 3, 1, 0).reshape(27, 16).contiguous()
+        out = dict(stem=dict(w=w27, scale=s, bias=b), blocks=[])
         for blk in cb.all_blocks():
             d = dict(kind=blk.kind, act=blk.act, cin=blk.cin, cout=blk.cout, mid=blk.mid, stride=blk.stride,
                      residual=blk.has_residual, se=se(blk.se) if hasattr(blk, "se") else None)
@@ -191,24 +192,26 @@ class Engine:
                 t = torch.empty(*shape, **z)
                 cache[key] = t
             return t
-        ops.input_pack(xin, b["img"], 1, 1)
         st = mb["stem"]
         cur = buf("stem", B, 112, 112, 16)
-        ops.conv2d(b["img"], st["w"], cur, kh=3, kw=1, stride=2, pad=0, seg_len=16, scale=st["scale"], bias=st["bias"],
-                   act="hswish")
+        ops.conv3x3s2_rgb(xin, st["w"], st["scale"], st["bias"], cur, act="hswish")
+
+        def pw(a, p, o, act=None, residual=None):   # 1x1 conv + folded BN (+ residual) (+ activation)
+            fn = ops.pointwise_conv if ops.pointwise_supported(a.shape[1], o.shape[1]) else ops.gemm
+            fn(a, p["w"], o, scale=p["scale"], bias=p["bias"], act=act, residual=residual)
         for i, d in enumerate(mb["blocks"]):
             Bc, H, W, C = cur.shape
             x_in = cur
             if d["kind"] == "cn":
                 p = d["pw"]
                 out = buf(f"o{i}", Bc, H, W, d["cout"])
-                ops.gemm(cur.view(-1, C), p["w"], out.view(-1, d["cout"]), scale=p["scale"], bias=p["bias"], act=d["act"])
+                pw(cur.view(-1, C), p, out.view(-1, d["cout"]), act=d["act"])
                 cur = out
                 continue
             if d["kind"] == "ir":
                 p = d["pw"]
                 mid = buf(f"m{i}", Bc, H, W, d["mid"])
-                ops.gemm(cur.view(-1, C), p["w"], mid.view(-1, d["mid"]), scale=p["scale"], bias=p["bias"], act=d["act"])
+                pw(cur.view(-1, C), p, mid.view(-1, d["mid"]), act=d["act"])
                 cur = mid
             q = d["dw"]
             Cm = cur.shape[3]
@@ -218,15 +221,17 @@ class Engine:
             if d["se"] is not None:
                 s_ = d["se"]
                 rd = s_["w1"].shape[0]
-                pooled, hid, gate = buf(f"sp{i}", Bc, Cm), buf(f"sh{i}", Bc, rd), buf(f"sg{i}", Bc, Cm)
-                ops.avgpool(dwo, pooled)
-                ops.gemm(pooled, s_["w1"], hid, bias=s_["b1"], act="relu")
-                ops.gemm(hid, s_["w2"], gate, bias=s_["b2"], act="hsigmoid")
-                ops.channel_scale(dwo, gate)
+                if ops.squeeze_excite_supported(Ho * Wo, Cm, rd):   # every block of mobilenetv3_small_100 at 224x224
+                    ops.squeeze_excite(dwo, s_["w1"], s_["b1"], s_["w2"], s_["b2"])
+                else:
+                    pooled, hid, gate = buf(f"sp{i}", Bc, Cm), buf(f"sh{i}", Bc, rd), buf(f"sg{i}", Bc, Cm)
+                    ops.avgpool(dwo, pooled)
+                    ops.gemm(pooled, s_["w1"], hid, bias=s_["b1"], act="relu")
+                    ops.gemm(hid, s_["w2"], gate, bias=s_["b2"], act="hsigmoid")
+                    ops.channel_scale(dwo, gate)
             p = d["pwl"]
             out = buf(f"o{i}", Bc, Ho, Wo, d["cout"])
-            ops.gemm(dwo.view(-1, Cm), p["w"], out.view(-1, d["cout"]), scale=p["scale"], bias=p["bias"],
-                     residual=x_in.view(-1, d["cout"]) if d["residual"] else None)
+            pw(dwo.view(-1, Cm), p, out.view(-1, d["cout"]), residual=x_in.view(-1, d["cout"]) if d["residual"] else None)
             cur = out
         return cur
 
@@ -243,7 +248,7 @@ class Engine:
         z = dict(dtype=BF16, device=dev)
         b: Dict[str, torch.Tensor] = {}
         if m.backbone_name == "mobilenetv3":
-            b["img"] = torch.zeros(B, 226, 228, 4, **z)  # halo 1 top / left, 1 / 3 bottom / right; stays zero
+            pass                                          # its stem reads the fp32 input directly; maps in b["mb_maps"]
         elif m.cnn_backbone is not None:
             b["img"] = torch.zeros(B, 230, 232, 4, **z)  # halo stays zero forever
             hw = 56

@@ -583,6 +583,80 @@ def channel_scale(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     return x
 
 
+SE_MAX_LDS_BYTES = 160 * 1024
+
+
+def squeeze_excite_supported(HW: int, C: int, RD: int) -> bool:
+    """Whether one image's map fits the LDS budget of squeeze_excite (include/rvit.h, RVIT_SE_MAX_LDS_BYTES)."""
+    if C % 8 or RD % 8 or C > 4096 or C <= 0:
+        return False
+    return 2 * HW * C + 4 * ((512 // (C // 8)) * C + 2 * C + RD) <= SE_MAX_LDS_BYTES
+
+
+def squeeze_excite(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """x[b,h,w,c] *= hardsigmoid(w2 . relu(w1 . mean_hw(x[b]) + b1) + b2)[c], in place, one launch (timm SqueezeExcite)."""
+    _need_cuda(x, w1, b1, w2, b2)
+    B, H, W, C = x.shape
+    RD = w1.shape[0]
+    if x.dtype != BF16 or w1.dtype != BF16 or w2.dtype != BF16 or not (x.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()) \
+            or tuple(w1.shape) != (RD, C) or tuple(w2.shape) != (C, RD):
+        raise ValueError(f"squeeze_excite: x {tuple(x.shape)} / w1 {tuple(w1.shape)} / w2 {tuple(w2.shape)} mismatch (bf16)")
+    _vec_f32(b1, RD, "squeeze_excite: b1")
+    _vec_f32(b2, C, "squeeze_excite: b2")
+    with _Span("squeeze_excite", 4 * B * C * RD, 2 * _nbytes(x)):
+        check(_lib.load().rvit_squeeze_excite_bf16(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                   B, H * W, C, RD, _stream()), "rvit_squeeze_excite_bf16")
+    return x
+
+
+def pointwise_supported(K: int, N: int) -> bool:
+    """Whether pointwise_conv takes an [N, K] weight matrix (else: gemm with the same epilogue arguments)."""
+    return bool(_lib.load().rvit_pointwise_conv_supported(int(K), int(N)))
+
+
+def pointwise_conv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, scale: Optional[torch.Tensor] = None,
+                   bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                   act: Optional[str] = None) -> torch.Tensor:
+    """out[m, n] = act(scale[n] * (x[m, :] . w[n, :]) + bias[n] + residual[m, n]); x bf16 [M, K], w bf16 [N, K], out and
+    residual bf16 [M, N], all contiguous (an NHWC map viewed as rows of pixels)."""
+    _need_cuda(x, w, out)
+    M, K = x.shape
+    N = w.shape[0]
+    if x.dtype != BF16 or w.dtype != BF16 or out.dtype != BF16 or not (x.is_contiguous() and w.is_contiguous() and out.is_contiguous()) \
+            or tuple(w.shape) != (N, K) or tuple(out.shape) != (M, N):
+        raise ValueError(f"pointwise_conv: x {tuple(x.shape)} / w {tuple(w.shape)} / out {tuple(out.shape)} mismatch (bf16, contiguous)")
+    if residual is not None and (residual.dtype != BF16 or not residual.is_contiguous() or tuple(residual.shape) != (M, N)):
+        raise ValueError("pointwise_conv: residual must be bf16 [M, N] contiguous")
+    if scale is not None:
+        _vec_f32(scale, N, "pointwise_conv: scale")
+    if bias is not None:
+        _vec_f32(bias, N, "pointwise_conv: bias")
+    with _Span("pointwise_conv", 2 * M * K * N, _nbytes(x, out)):
+        check(_lib.load().rvit_pointwise_conv_bf16(x.data_ptr(), w.data_ptr(), scale.data_ptr() if scale is not None else None,
+                                                   bias.data_ptr() if bias is not None else None,
+                                                   residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                                                   M, K, N, _ACT[act], _stream()), "rvit_pointwise_conv_bf16")
+    return out
+
+
+def conv3x3s2_rgb(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, out: torch.Tensor,
+                  act: Optional[str] = None) -> torch.Tensor:
+    """conv 3x3 / stride 2 / pad 1 (3 -> 16) + scale/bias + activation from the fp32 NCHW input; w f32 [27, 16] with
+    k = (kh*3 + kw)*3 + ci; out bf16 NHWC [B, H/2, W/2, 16]."""
+    _need_cuda(x, w, scale, bias, out)
+    B, Cin, H, W = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous() or Cin != 3 or H % 2 or W % 2 or w.dtype != torch.float32 \
+            or tuple(w.shape) != (27, 16) or not w.is_contiguous() or out.dtype != BF16 or not out.is_contiguous() \
+            or tuple(out.shape) != (B, H // 2, W // 2, 16):
+        raise ValueError(f"conv3x3s2_rgb: x {tuple(x.shape)} f32 NCHW (H, W even), w f32 [27,16], out bf16 {(B, H // 2, W // 2, 16)}")
+    _vec_f32(scale, 16, "conv3x3s2_rgb: scale")
+    _vec_f32(bias, 16, "conv3x3s2_rgb: bias")
+    with _Span("conv3x3s2_rgb", 2 * B * (H // 2) * (W // 2) * 27 * 16, _nbytes(x, out)):
+        check(_lib.load().rvit_conv3x3s2_rgb_f32_fwd(x.data_ptr(), w.data_ptr(), scale.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                     B, H, W, 16, _ACT[act], _stream()), "rvit_conv3x3s2_rgb_f32_fwd")
+    return out
+
+
 def attention_s64(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, scale: Optional[float] = None) -> torch.Tensor:
     """attention() for S <= 64 with the arithmetic of encoder_attn's core (bit-identical to the fused kernel)."""
     _need_cuda(qkv, out)
