@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 17
+#define RVIT_ABI_VERSION 18
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -207,6 +207,36 @@ int rvit_pointwise_conv_bf16(const void* x, const void* w, const float* scale, c
 int rvit_pointwise_conv_supported(int K, int N);
 int rvit_conv3x3s2_rgb_f32_fwd(const float* x_nchw, const float* w, const float* scale, const float* bias, void* out, int B,
                                int H, int W, int Cout, int act, void* stream);
+
+/* Training pass of the MobileNetV3 stem (model.train() forward and its autograd, train_vit.py:145-146,939).
+ *   rvit_bn_generic_{stats,apply,bwd}: train-mode nn.BatchNorm2d on an NHWC bf16 map [M, C] of any C % 8 == 0
+ *     (rvit_bn_* needs the resnet widths), fused with the activation that follows it in timm's BatchNormAct2d
+ *     (RVIT_ACT_NONE / RELU / HSWISH) and an optional residual:
+ *       stats: sums[0:C] += sum_m y, sums[C:2C] += sum_m y^2;
+ *       apply: z = act(gamma * (y - mean) * rstd + beta + residual), running statistics updated when given;
+ *       bwd:   g = dz * act'(u) with u recomputed from y; bsums += (sum g, sum g * xhat);
+ *              dy = gamma * rstd * (g - bsums1 / M - xhat * bsums2 / M); dgamma += bsums2; dbeta += bsums1.
+ *     sums / bsums are zeroed by the caller.  The reductions are ordered (bit-reproducible): `workspace` is required.
+ *   rvit_dwconv_dgrad_bf16 / rvit_dwconv_wgrad_bf16: gradients of the depthwise convolution of rvit_dwconv_fwd_bf16
+ *     (same geometry arguments; H, W are the INPUT map's): dx [B, H, W, C]; dw f32 [C, K*K] += (the parameter's own
+ *     layout [C, 1, K, K]); ordered, `workspace` required.
+ *   rvit_channel_affine_nhwc: out[b, p, c] = x[b, p, c] * gate[b, c] + add[b, c] (add may be NULL, out may be x): the
+ *     squeeze-excite multiply with a separate output, and its backward.
+ *   rvit_channel_dot_nhwc: out[b, c] = (sum_p a[b, p, c] * x[b, p, c]) * hardsigmoid'(gate[b, c]) (gate may be NULL): the
+ *     gradient of the squeeze-excite gate's pre-activation, bf16 [B, C]. */
+int rvit_bn_generic_stats(const void* y, int64_t M, int C, float* sums, void* workspace, int64_t workspace_bytes, void* stream);
+int rvit_bn_generic_apply(const void* y, const float* sums, const float* gamma, const float* beta, const void* residual,
+                          void* z, int64_t M, int C, float eps, int act, float momentum, float* running_mean,
+                          float* running_var, void* stream);
+int rvit_bn_generic_bwd(const void* dz, const void* y, const float* fsums, float* bsums, const float* gamma, const float* beta,
+                        void* dy, float* dgamma, float* dbeta, int64_t M, int C, float eps, int act, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+int rvit_dwconv_dgrad_bf16(const void* dy, const void* w, void* dx, int B, int H, int W, int C, int K, int stride, int pad,
+                           void* stream);
+int rvit_dwconv_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int W, int C, int K, int stride, int pad,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int rvit_channel_affine_nhwc(const void* x, const void* gate, const void* add, void* out, int B, int HW, int C, void* stream);
+int rvit_channel_dot_nhwc(const void* a, const void* x, const void* gate, void* out, int B, int HW, int C, void* stream);
 
 /* Fused stem entry for inference: conv 7x7/2 pad 3 (3->64) + folded BatchNorm (scale, bias) + ReLU +
  * max-pool 3x3/2 pad 1 in one kernel; the 112x112x64 map never reaches HBM.  Replaces timm resnet

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 17
+ABI_VERSION = 18
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -63,6 +63,13 @@ SIGNATURES = {
     "rvit_avgpool_nhwc": ([P, P, I, I, I, P], c_int),
     "rvit_channel_scale_nhwc": ([P, P, I, I, I, P], c_int),
     "rvit_squeeze_excite_bf16": ([P, P, P, P, P, I, I, I, I, P], c_int),
+    "rvit_bn_generic_stats": ([P, L, I, P, P, L, P], c_int),
+    "rvit_bn_generic_apply": ([P, P, P, P, P, P, L, I, F, I, F, P, P, P], c_int),
+    "rvit_bn_generic_bwd": ([P, P, P, P, P, P, P, P, P, L, I, F, I, P, L, P], c_int),
+    "rvit_dwconv_dgrad_bf16": ([P, P, P, I, I, I, I, I, I, I, P], c_int),
+    "rvit_dwconv_wgrad_bf16": ([P, P, P, I, I, I, I, I, I, I, P, L, P], c_int),
+    "rvit_channel_affine_nhwc": ([P, P, P, P, I, I, I, P], c_int),
+    "rvit_channel_dot_nhwc": ([P, P, P, P, I, I, I, P], c_int),
     "rvit_pointwise_conv_bf16": ([P, P, P, P, P, P, L, I, I, I, P], c_int),
     "rvit_pointwise_conv_supported": ([I, I], c_int),
     "rvit_conv3x3s2_rgb_f32_fwd": ([P, P, P, P, P, I, I, I, I, I, P], c_int),

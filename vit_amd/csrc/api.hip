@@ -334,6 +334,36 @@ int rvit_squeeze_excite_bf16(void* x, const void* w1, const float* b1, const voi
                              int RD, void* stream) {
   return rvit_squeeze_excite_impl(x, w1, b1, w2, b2, B, HW, C, RD, (hipStream_t)stream);
 }
+int rvit_bn_generic_stats(const void* y, int64_t M, int C, float* sums, void* workspace, int64_t workspace_bytes, void* stream) {
+  return rvit_mb_bn_stats_impl(y, (long)M, C, sums, workspace, (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), (hipStream_t)stream);
+}
+int rvit_bn_generic_apply(const void* y, const float* sums, const float* gamma, const float* beta, const void* residual,
+                          void* z, int64_t M, int C, float eps, int act, float momentum, float* running_mean,
+                          float* running_var, void* stream) {
+  return rvit_mb_bn_apply_impl(y, sums, gamma, beta, residual, z, (long)M, C, eps, act, momentum, running_mean, running_var,
+                               (hipStream_t)stream);
+}
+int rvit_bn_generic_bwd(const void* dz, const void* y, const float* fsums, float* bsums, const float* gamma, const float* beta,
+                        void* dy, float* dgamma, float* dbeta, int64_t M, int C, float eps, int act, void* workspace,
+                        int64_t workspace_bytes, void* stream) {
+  return rvit_mb_bn_bwd_impl(dz, y, fsums, bsums, gamma, beta, dy, dgamma, dbeta, (long)M, C, eps, act, workspace,
+                             (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), (hipStream_t)stream);
+}
+int rvit_dwconv_dgrad_bf16(const void* dy, const void* w, void* dx, int B, int H, int W, int C, int K, int stride, int pad,
+                           void* stream) {
+  return rvit_dwconv_dgrad_impl(dy, w, dx, B, H, W, C, K, stride, pad, (hipStream_t)stream);
+}
+int rvit_dwconv_wgrad_bf16(const void* dy, const void* x, float* dw, int B, int H, int W, int C, int K, int stride, int pad,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+  return rvit_dwconv_wgrad_impl(dy, x, dw, B, H, W, C, K, stride, pad, workspace,
+                                (size_t)(workspace_bytes > 0 ? workspace_bytes : 0), (hipStream_t)stream);
+}
+int rvit_channel_affine_nhwc(const void* x, const void* gate, const void* add, void* out, int B, int HW, int C, void* stream) {
+  return rvit_channel_affine_impl(x, gate, add, out, B, HW, C, (hipStream_t)stream);
+}
+int rvit_channel_dot_nhwc(const void* a, const void* x, const void* gate, void* out, int B, int HW, int C, void* stream) {
+  return rvit_channel_dot_impl(a, x, gate, out, B, HW, C, (hipStream_t)stream);
+}
 int rvit_pointwise_conv_bf16(const void* x, const void* w, const float* scale, const float* bias, const void* residual,
                              void* out, int64_t M, int K, int N, int act, void* stream) {
   return rvit_pointwise_impl(x, w, scale, bias, residual, out, (long)M, K, N, act, (hipStream_t)stream);

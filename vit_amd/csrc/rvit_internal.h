@@ -156,6 +156,19 @@ int rvit_avgpool_impl(const void* x, void* out, int B, int HW, int C, hipStream_
 int rvit_channel_scale_impl(void* x, const void* gate, int B, int HW, int C, hipStream_t st);
 int rvit_squeeze_excite_impl(void* x, const void* w1, const float* b1, const void* w2, const float* b2, int B, int HW, int C,
                              int RD, hipStream_t st);
+int rvit_mb_bn_stats_impl(const void* y, long M, int C, float* sums, void* ws, size_t ws_bytes, hipStream_t st);
+int rvit_mb_bn_apply_impl(const void* y, const float* sums, const float* gamma, const float* beta, const void* res, void* z,
+                          long M, int C, float eps, int act, float momentum, float* running_mean, float* running_var,
+                          hipStream_t st);
+int rvit_mb_bn_bwd_impl(const void* dz, const void* y, const float* fsums, float* bsums, const float* gamma, const float* beta,
+                        void* dy, float* dgamma, float* dbeta, long M, int C, float eps, int act, void* ws, size_t ws_bytes,
+                        hipStream_t st);
+int rvit_dwconv_dgrad_impl(const void* dy, const void* w, void* dx, int B, int H, int W, int C, int K, int stride, int pad,
+                           hipStream_t st);
+int rvit_dwconv_wgrad_impl(const void* dy, const void* x, float* dw, int B, int H, int W, int C, int K, int stride, int pad,
+                           void* ws, size_t ws_bytes, hipStream_t st);
+int rvit_channel_affine_impl(const void* x, const void* gate, const void* add, void* out, int B, int HW, int C, hipStream_t st);
+int rvit_channel_dot_impl(const void* a, const void* x, const void* gate, void* out, int B, int HW, int C, hipStream_t st);
 long rvit_pointwise_lds_bytes(int K, int N);
 int rvit_pointwise_impl(const void* x, const void* w, const float* scale, const float* bias, const void* residual, void* out,
                         long M, int K, int N, int act, hipStream_t st);
