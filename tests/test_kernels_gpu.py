@@ -65,6 +65,90 @@ def test_gemm_256x256_tile_bit_identical(dev, M, N, K, auto):
         _close(outs[1][2], a.float().cpu() @ w.float().cpu().T, 1e-4, 1e-4, "256x256 f32 out")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (700, 520, 320), (1000, 72, 1024), (513, 257, 192), (77, 11, 128),
+                                   (4096, 1024, 768), (50432, 768, 3072)])
+def test_gemm_8phase_tile_bit_identical(dev, M, N, K):
+    """The eight-wave 256x256 kernel with the four-phase K tile (tile 5, csrc/gemm8p.hip; what the ViT-B / ViT-L Linears
+    run) against the 256x64 tile: same K order, so identical bits through every epilogue form; ragged M / N tiles, odd
+    and even K-tile counts, and repeated launches (a race between the DMA ring and the fragment reads would show as
+    rare differing tiles)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias, scale = torch.randn(N, generator=g).to(dev), (torch.rand(N, generator=g) + 0.5).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    outs = []
+    for tile in (1, 5):
+        o1 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(a, w, o1, bias=bias, scale=scale, residual=res, act="gelu", preact=pre, tile=tile)
+        o2 = torch.empty(M, N, dtype=torch.float32, device=dev)
+        ops.gemm(a, w, o2, tile=tile)
+        outs.append((o1, pre, o2))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    for _ in range(5 if M > 4096 else 20):
+        o3 = torch.empty(M, N, dtype=torch.float32, device=dev)
+        ops.gemm(a, w, o3, tile=5)
+        assert torch.equal(o3, outs[0][2])
+    if M <= 1024:
+        _close(outs[1][2], a.float().cpu() @ w.float().cpu().T, 1e-4, 1e-4, "8-phase f32 out")
+
+
+@pytest.mark.parametrize("form", ["gate_gelu_grad", "gate_relu_bf16res", "drop_pre", "drop_post", "periodic_res_remap",
+                                  "lean_plain", "lean_bias", "lean_bias_gelu", "lean_bias_gelu_preact", "lean_bias_res",
+                                  "scale_only"])
+def test_gemm_8phase_epilogue_forms(dev, form):
+    """Every epilogue form through the split (load / apply) epilogue of the eight-wave kernel equals the 256x64 tile's
+    single-function epilogue bit for bit: gates of a saved pre-activation, bf16 and periodic residuals, both dropout
+    positions, the output row remap; ragged M and N."""
+    from vit_amd import ops
+    M, N, K = 1100, 328, 256
+    g = torch.Generator().manual_seed(len(form))
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    kw = dict(bias=bias)
+    rows_out = M
+    if form.startswith("lean") or form == "scale_only":   # the compile-time epilogue forms of csrc/gemm8p.hip
+        kw = {} if form == "lean_plain" else dict(bias=bias)
+        if "gelu" in form:
+            kw["act"] = "gelu"
+        if "preact" in form:
+            kw["preact"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        if "res" in form:
+            kw["residual"] = torch.randn(M, N, generator=g).to(dev)
+        if form == "scale_only":
+            kw = dict(scale=(torch.rand(N, generator=g) + 0.5).to(dev))
+    elif form == "gate_gelu_grad":
+        kw.update(gate=_bf(torch.randn(M, N, generator=g)).to(dev), gate_mode="gelu_grad")
+    elif form == "gate_relu_bf16res":
+        kw.update(gate=_bf(torch.randn(M, N, generator=g)).to(dev), gate_mode="relu_mask",
+                  residual=_bf(torch.randn(M, N, generator=g)).to(dev), act="relu")
+    elif form == "drop_pre":
+        kw.update(residual=torch.randn(M, N, generator=g).to(dev), drop=("pre_residual", 0.1, 0x1234567887654321))
+    elif form == "drop_post":
+        kw.update(act="gelu", preact=torch.empty(M, N, dtype=torch.bfloat16, device=dev), drop=("post_act", 0.25, 77))
+    else:
+        kw.update(residual=torch.randn(50, N, generator=g).to(dev), residual_period=50, row_group=50, row_extra=1)
+        rows_out = (M // 50) * 51
+    outs = []
+    for tile in (1, 5):
+        res = []
+        for dt in (torch.float32, torch.bfloat16):
+            o = torch.zeros(rows_out, N, dtype=dt, device=dev)
+            if "preact" in kw:
+                kw["preact"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm(a, w, o, tile=tile, **kw)
+            res.append(o)
+            if "preact" in kw:
+                res.append(kw["preact"])
+        outs.append(res)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y), form
+
+
 def test_gemm_identity_asymmetric(dev):
     """A = I with an asymmetric B catches a transposed C write (guide §3)."""
     from vit_amd import ops

@@ -351,6 +351,7 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   const bool big = big_plain || big_conv;
   int cfg;
   if (forced) cfg = forced;
+  else if (big_plain && rvit_gemm8p_ok(a)) cfg = 5;   // eight waves, four-phase K tile (gemm8p.hip): 0.92-1.13 vs 0.59-0.90 PFLOP/s on the ViT-B Linears, same bits
   else if (big) cfg = 4;
   else if (((a.M + 255) / 256) * n64 >= 384) cfg = 1;
   else if (((a.M + 127) / 128) * n64 >= 256) cfg = 2;
@@ -360,6 +361,7 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     case 2: return launch_cfg<128, 64, 4, 1, 2>(a, stream);
     case 3: return launch_cfg<64, 64, 2, 1, 2>(a, stream);
     case 4: return launch_cfg<256, 256, 4, 4, 2>(a, stream);
+    case 5: return rvit_gemm8p(a, stream);
     // 64x64 wave tiles (<256,64,4>, <128,64,2>, <512,64,8>: fewer LDS reads per MFMA) measured 20-35 % slower:
     // this loop is latency-bound and wants the 16 waves per CU (profiles/r01_tile_sweep_wave64.txt)
     default: rvit_set_error("gemm: unknown tile config %d", cfg); return RVIT_EINVAL;

@@ -102,3 +102,118 @@ __device__ __forceinline__ void rvit_gemm_epilogue_row8(const GemmArgs& p, float
     }
   }
 }
+
+// The same epilogue split into its loads and the rest, for kernels that run it in several passes over one tile
+// (gemm8p.hip).  vmcnt counts loads AND stores in issue order on gfx950: a pass that loads its row operands (residual,
+// gate) or the per-column scale / bias right before using them waits for every store of the pass before it to reach L2
+// (~1 us per pass: 8 of the 30 us a ViT-B fc1 tile took).  Split, the column operands are read once per tile, a pass's
+// row operands are requested BEFORE the previous pass's stores are issued, and the stores are never waited for.
+// vec form only (p.vec != 0); same operations in the same order as rvit_gemm_epilogue_row8: identical bits.
+struct EpiCols { float sc[8], bi[8]; };
+struct EpiRow { long orow; float4 ra, rb; uint4 g; };
+
+__device__ __forceinline__ void rvit_epi_cols_load(const GemmArgs& p, int n, EpiCols& c) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { c.sc[e] = 1.f; c.bi[e] = 0.f; }
+  if (p.scale) {
+    const float4 a = *reinterpret_cast<const float4*>(p.scale + n);
+    const float4 b = *reinterpret_cast<const float4*>(p.scale + n + 4);
+    c.sc[0] = a.x; c.sc[1] = a.y; c.sc[2] = a.z; c.sc[3] = a.w; c.sc[4] = b.x; c.sc[5] = b.y; c.sc[6] = b.z; c.sc[7] = b.w;
+  }
+  if (p.bias) {
+    const float4 a = *reinterpret_cast<const float4*>(p.bias + n);
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    c.bi[0] = a.x; c.bi[1] = a.y; c.bi[2] = a.z; c.bi[3] = a.w; c.bi[4] = b.x; c.bi[5] = b.y; c.bi[6] = b.z; c.bi[7] = b.w;
+  }
+}
+
+// m must be a valid logical row (callers clamp rows past M and mask the store instead)
+__device__ __forceinline__ void rvit_epi_row_load(const GemmArgs& p, long m, int n, EpiRow& r) {
+  long orow = m;
+  if (p.row_group > 0) {
+    const long g = m / p.row_group;
+    orow = g * (p.row_group + p.row_extra) + (m - g * p.row_group) + p.row_extra;
+  }
+  r.orow = orow;
+  const long rrow = p.r_period > 0 ? (m % p.r_period) : orow;
+  if (p.gate) r.g = *reinterpret_cast<const uint4*>(p.G + orow * p.ldg + n);
+  if (p.R) {
+    if (p.r_f32) {
+      const float* rp = (const float*)p.R + rrow * p.ldr + n;
+      r.ra = *reinterpret_cast<const float4*>(rp);
+      r.rb = *reinterpret_cast<const float4*>(rp + 4);
+    } else {
+      const uint4 q = *reinterpret_cast<const uint4*>((const bf16*)p.R + rrow * p.ldr + n);
+      r.ra = make_float4(__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w));
+    }
+  }
+}
+
+__device__ __forceinline__ void rvit_epi_row_apply(const GemmArgs& p, float (&v)[8], const EpiRow& r, const EpiCols& c,
+                                                   int n, bool store) {
+  const long orow = r.orow;
+  if (p.scale) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= c.sc[e];
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += c.bi[e];
+  }
+  if (p.gate) {
+    const uint4 gq = r.g;
+    const float gv[8] = {bf16_lo(gq.x), bf16_hi(gq.x), bf16_lo(gq.y), bf16_hi(gq.y),
+                         bf16_lo(gq.z), bf16_hi(gq.z), bf16_lo(gq.w), bf16_hi(gq.w)};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      v[e] *= p.gate == RVIT_GATE_GELU_GRAD ? gelu_erf_grad(gv[e]) : (gv[e] > 0.f ? 1.f : 0.f);
+  }
+  if (p.C2 && store) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p.C2 + orow * p.ldc2 + n) = o;
+  }
+  if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) {
+    const uint32_t di = (uint32_t)(orow * p.N + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
+  }
+  if (p.R) {
+    if (p.r_f32) {
+      v[0] += r.ra.x; v[1] += r.ra.y; v[2] += r.ra.z; v[3] += r.ra.w;
+      v[4] += r.rb.x; v[5] += r.rb.y; v[6] += r.rb.z; v[7] += r.rb.w;
+    } else {
+      const uint32_t q0 = __float_as_uint(r.ra.x), q1 = __float_as_uint(r.ra.y), q2 = __float_as_uint(r.ra.z),
+                     q3 = __float_as_uint(r.ra.w);
+      v[0] += bf16_lo(q0); v[1] += bf16_hi(q0); v[2] += bf16_lo(q1); v[3] += bf16_hi(q1);
+      v[4] += bf16_lo(q2); v[5] += bf16_hi(q2); v[6] += bf16_lo(q3); v[7] += bf16_hi(q3);
+    }
+  }
+  if (p.act == RVIT_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  } else if (p.act == RVIT_ACT_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+  } else if (p.act >= RVIT_ACT_HSWISH) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = rvit_apply_act(v[e], p.act);
+  }
+  if (p.drop_mode == RVIT_DROP_POST_ACT) {
+    const uint32_t di = (uint32_t)(orow * p.N + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
+  }
+  if (!store) return;
+  if (p.c_f32) {
+    float* cp = (float*)p.C + orow * p.ldc + n;
+    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>((bf16*)p.C + orow * p.ldc + n) = o;
+  }
+}

@@ -42,6 +42,8 @@ struct GemmArgs {
 };
 
 int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream);
+bool rvit_gemm8p_ok(const GemmArgs& a);                       // gemm8p.hip (256x256 tile, eight waves, 8-phase K loop)
+int rvit_gemm8p(const GemmArgs& a, hipStream_t stream);
 bool rvit_conv3x3_direct_ok(const GemmArgs& a);               // conv3x3.hip
 int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t stream);
 bool rvit_conv3x3_c64_ok(const GemmArgs& a);                  // conv3x3_c64.hip (64 -> 64 channels, weights resident)
