@@ -65,13 +65,14 @@ def test_gemm_256x256_tile_bit_identical(dev, M, N, K, auto):
         _close(outs[1][2], a.float().cpu() @ w.float().cpu().T, 1e-4, 1e-4, "256x256 f32 out")
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (700, 520, 320), (1000, 72, 1024), (513, 257, 192), (77, 11, 128),
-                                   (4096, 1024, 768), (50432, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (700, 520, 384), (1000, 72, 1024), (513, 264, 256), (77, 24, 128),
+                                   (4096, 1024, 768), (20000, 1288, 256), (50432, 768, 3072)])
 def test_gemm_8phase_tile_bit_identical(dev, M, N, K):
     """The eight-wave 256x256 kernel with the four-phase K tile (tile 5, csrc/gemm8p.hip; what the ViT-B / ViT-L Linears
-    run) against the 256x64 tile: same K order, so identical bits through every epilogue form; ragged M / N tiles, odd
-    and even K-tile counts, and repeated launches (a race between the DMA ring and the fragment reads would show as
-    rare differing tiles)."""
+    run) against the 256x64 tile: same K order, so identical bits through every epilogue form; ragged M / N tiles, one
+    to many output tiles per persistent workgroup (the staging stream runs on into the next output tile), K loops of 2
+    to 48 K tiles, and repeated launches (a race between the DMA ring and the fragment reads would show as rare
+    differing tiles)."""
     from vit_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     a = _bf(torch.randn(M, K, generator=g)).to(dev)
@@ -104,7 +105,7 @@ def test_gemm_8phase_epilogue_forms(dev, form):
     single-function epilogue bit for bit: gates of a saved pre-activation, bf16 and periodic residuals, both dropout
     positions, the output row remap; ragged M and N."""
     from vit_amd import ops
-    M, N, K = 1100, 328, 256
+    M, N, K = 4500, 1288, 256      # 18 x 6 tiles of 256 x 256: no workgroup runs out of tiles after one
     g = torch.Generator().manual_seed(len(form))
     a = _bf(torch.randn(M, K, generator=g)).to(dev)
     w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)

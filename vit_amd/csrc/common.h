@@ -149,27 +149,54 @@ __device__ __forceinline__ float rvit_apply_act(float x, int act) {
 
 // Counter-based dropout (nn.Dropout of train_vit.py:100,107,125 and the attention-probability
 // dropout of torch functional.py:6569-6570).  Element `idx` of a dropout site keyed by (k0, k1) is
-// kept iff the top 24 bits of a two-round integer hash reach the threshold; forward and backward
-// regenerate the same decision from (key, idx), no mask is stored.
+// kept iff 16 bits of an integer hash of (key, idx >> 1) reach the threshold: one 32-bit hash decides TWO
+// neighbouring elements (its low half the even one, its high half the odd one).  Forward and backward
+// regenerate the same decision from (key, idx), no mask is stored.  Cost matters: the hash runs once per
+// output element in GEMM epilogues and on every attention probability, and 32-bit integer multiplies issue
+// at a quarter of the vector rate: the first form (two full rounds per ELEMENT, four multiplies) cost more
+// vector-ALU time in a ViT-B linear1 epilogue than the tile's whole K loop took on the matrix pipe; this one
+// is three multiplies per PAIR.  The drop probability is quantised to 1/65536 (p = 0.1 -> 0.100006).
 __device__ __forceinline__ uint32_t rvit_mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
 struct DropKey {
-  uint32_t k0, k1, thresh;  // thresh = round(p * 2^24); 0 disables
+  uint32_t k0, k1, thresh;  // thresh = round(p * 2^16); 0 disables
   float scale;              // 1 / (1 - p)
 };
 __host__ __device__ inline DropKey make_drop_key(float p, uint64_t seed) {
   DropKey k;
   k.k0 = (uint32_t)seed;
   k.k1 = (uint32_t)(seed >> 32);
-  k.thresh = p > 0.f ? (uint32_t)(p * 16777216.0f + 0.5f) : 0u;
+  k.thresh = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
   k.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   return k;
 }
+// a multiply that no later add is contracted with (hipcc inlines __fmul_rn as a plain, contractable `*`): left to the
+// compiler, x * mult + residual becomes one fma in some kernels and not in others, and their outputs differ in the last bit
+__device__ __forceinline__ float rvit_mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+// 32 decision bits for the element pair (2 * pair, 2 * pair + 1)
+__device__ __forceinline__ uint32_t rvit_drop_hash(const DropKey& k, uint32_t pair) {
+  uint32_t h = rvit_mix32(pair + k.k0);
+  h = (h ^ k.k1) * 0x9E3779B1U;
+  return h ^ (h >> 15);
+}
 __device__ __forceinline__ float drop_mult(const DropKey& k, uint32_t idx) {
-  const uint32_t h = rvit_mix32(rvit_mix32(idx + k.k0) ^ k.k1);
-  return (h >> 8) >= k.thresh ? k.scale : 0.f;
+  const uint32_t h = rvit_drop_hash(k, idx >> 1);
+  const uint32_t bits = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
+  return bits >= k.thresh ? k.scale : 0.f;
+}
+// eight consecutive elements starting at an EVEN index: four hashes
+__device__ __forceinline__ void drop_mult8(const DropKey& k, uint32_t idx0, float (&v)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = rvit_drop_hash(k, (idx0 >> 1) + q);
+    v[2 * q] = rvit_mul_rn(v[2 * q], (h & 0xffffu) >= k.thresh ? k.scale : 0.f);
+    v[2 * q + 1] = rvit_mul_rn(v[2 * q + 1], (h >> 16) >= k.thresh ? k.scale : 0.f);
+  }
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {

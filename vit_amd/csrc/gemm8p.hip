@@ -48,6 +48,16 @@ __device__ __forceinline__ void p8_glds16(const void* src, char* lds_dst_wave_ba
   __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst_wave_base, 16, 0, 0);
 }
 
+typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
+// nt (wave-uniform): nontemporal store.  The output of a wide Linear is far bigger than the L2 and its next reader is
+// another kernel; kept out of the L2, the stores delay the next workgroup's first operand loads less (ViT-B in_proj /
+// linear1, ViT-L linear1: +4-5 %).  Outputs that fit the 256 MB memory-side cache lose 4 % instead: the host decides.
+__device__ __forceinline__ void p8_store16(void* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, int nt) {
+  const p8_u32x4 v = {a, b, c, d};
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<p8_u32x4*>(dst));
+  else *reinterpret_cast<p8_u32x4*>(dst) = v;
+}
+
 #define P8_SB() __builtin_amdgcn_sched_barrier(0)
 #define P8_BAR() __builtin_amdgcn_s_barrier()
 
@@ -56,12 +66,13 @@ __device__ __forceinline__ void p8_glds16(const void* src, char* lds_dst_wave_ba
 // residual: the forms of the encoder's Linears in inference and of the plain input-gradient products.  The generic
 // epilogue issues ~170 vector instructions per 16-row fragment row and wave whatever the flags say (measured: 1,350
 // cycles per fragment row, 5.4 us per tile before a single byte is stored); a lean one issues what its form needs.
-constexpr int P8F_BIAS = 1, P8F_GELU = 2, P8F_C2 = 4, P8F_R32 = 8, P8F_CF32 = 16;
+constexpr int P8F_BIAS = 1, P8F_GELU = 2, P8F_C2 = 4, P8F_R32 = 8, P8F_CF32 = 16, P8F_DROP_PRE = 32, P8F_DROP_POST = 64,
+              P8F_GGELU = 128;   // dropout before the residual / after the activation; gate = gelu'(saved pre-activation)
 
 #ifdef P8_STAMPS
 #define P8_STAMP(i) do { if (threadIdx.x == 0) { stamps[blockIdx.x * 16 + (i)] = wall_clock64(); stamps[blockIdx.x * 16 + 8 + (i)] = __builtin_readcyclecounter(); } } while (0)
 template <int MODE>
-__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p, unsigned long long* stamps) {
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p, const int nt_store, unsigned long long* stamps) {
   P8_STAMP(0);
   if (threadIdx.x == 0) {
     unsigned hwid, xcc;
@@ -72,7 +83,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p, unsigned 
 #else
 #define P8_STAMP(i)
 template <int MODE>
-__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p, const int nt_store) {
 #endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -285,13 +296,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
     }
     P8_STAMP(5);
     float4 rn[2][2];
-    if constexpr ((MODE & P8F_R32) != 0) {
+    uint4 gn[2];
+    if constexpr ((MODE & (P8F_R32 | P8F_GGELU)) != 0) {
       const long mr = m0 < mlast ? m0 : mlast;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        const float* rp = (const float*)p.R + mr * p.ldr + nl[pr];
-        rn[pr][0] = *reinterpret_cast<const float4*>(rp);
-        rn[pr][1] = *reinterpret_cast<const float4*>(rp + 4);
+        if constexpr ((MODE & P8F_R32) != 0) {
+          const float* rp = (const float*)p.R + mr * p.ldr + nl[pr];
+          rn[pr][0] = *reinterpret_cast<const float4*>(rp);
+          rn[pr][1] = *reinterpret_cast<const float4*>(rp + 4);
+        }
+        if constexpr ((MODE & P8F_GGELU) != 0) gn[pr] = *reinterpret_cast<const uint4*>(p.G + mr * p.ldg + nl[pr]);
       }
     }
 #pragma unroll
@@ -299,17 +314,24 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
       if (i0 == 1) P8_STAMP(6);
       const long m = m0 + i0 * 16;
       float4 rc[2][2];
-      if constexpr ((MODE & P8F_R32) != 0) {
+      uint4 gc[2];
+      if constexpr ((MODE & (P8F_R32 | P8F_GGELU)) != 0) {
         const long m1 = m0 + (i0 < 7 ? i0 + 1 : 7) * 16;   // rows past the matrix re-read its last row: never used
         const long mr = m1 < mlast ? m1 : mlast;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          rc[pr][0] = rn[pr][0];
-          rc[pr][1] = rn[pr][1];
-          if (i0 < 7) {
-            const float* rp = (const float*)p.R + mr * p.ldr + nl[pr];
-            rn[pr][0] = *reinterpret_cast<const float4*>(rp);
-            rn[pr][1] = *reinterpret_cast<const float4*>(rp + 4);
+          if constexpr ((MODE & P8F_R32) != 0) {
+            rc[pr][0] = rn[pr][0];
+            rc[pr][1] = rn[pr][1];
+            if (i0 < 7) {
+              const float* rp = (const float*)p.R + mr * p.ldr + nl[pr];
+              rn[pr][0] = *reinterpret_cast<const float4*>(rp);
+              rn[pr][1] = *reinterpret_cast<const float4*>(rp + 4);
+            }
+          }
+          if constexpr ((MODE & P8F_GGELU) != 0) {
+            gc[pr] = gn[pr];
+            if (i0 < 7) gn[pr] = *reinterpret_cast<const uint4*>(p.G + mr * p.ldg + nl[pr]);
           }
         }
       }
@@ -328,6 +350,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bi[pr][e];
         }
+        if constexpr ((MODE & P8F_GGELU) != 0) {
+          const uint4 gq = gc[pr];
+          const float gv[8] = {bf16_lo(gq.x), bf16_hi(gq.x), bf16_lo(gq.y), bf16_hi(gq.y),
+                               bf16_lo(gq.z), bf16_hi(gq.z), bf16_lo(gq.w), bf16_hi(gq.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_grad(gv[e]);
+        }
         if constexpr ((MODE & P8F_C2) != 0) {
           if (ok) {
             uint4 o;
@@ -336,6 +365,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
             *reinterpret_cast<uint4*>(p.C2 + m * p.ldc2 + nl[pr]) = o;
           }
         }
+        if constexpr ((MODE & P8F_DROP_PRE) != 0) drop_mult8(p.drop, (uint32_t)(m * p.N + nl[pr]), v);
         if constexpr ((MODE & P8F_R32) != 0) {
           v[0] += rc[pr][0].x; v[1] += rc[pr][0].y; v[2] += rc[pr][0].z; v[3] += rc[pr][0].w;
           v[4] += rc[pr][1].x; v[5] += rc[pr][1].y; v[6] += rc[pr][1].z; v[7] += rc[pr][1].w;
@@ -344,16 +374,17 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmArgs p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
         }
+        if constexpr ((MODE & P8F_DROP_POST) != 0) drop_mult8(p.drop, (uint32_t)(m * p.N + nl[pr]), v);
         if (ok) {
+          // nontemporal stores (P8_NT): the output of a large Linear is far bigger than the L2 and its next reader is
+          // another kernel; kept out of the L2, the stores no longer delay the next workgroup's first operand loads
           if constexpr ((MODE & P8F_CF32) != 0) {
             float* cp = (float*)p.C + m * p.ldc + nl[pr];
-            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(cp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            p8_store16(cp, __float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]), nt_store);
+            p8_store16(cp + 4, __float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]), nt_store);
           } else {
-            uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
-            o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
-            *reinterpret_cast<uint4*>((bf16*)p.C + m * p.ldc + nl[pr]) = o;
+            p8_store16((bf16*)p.C + m * p.ldc + nl[pr], pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                              pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]), nt_store);
           }
         }
       }
@@ -460,12 +491,14 @@ int rvit_gemm8p(const GemmArgs& a, hipStream_t stream) {
     rvit_set_error("gemm: too many tiles (%ld)", tiles);
     return RVIT_EINVAL;
   }
+  const int nt_store = (double)a.M * a.N * (a.c_f32 ? 4 : 2) > 200e6;
   // lean epilogue forms (see the kernel): everything a form does not name must be absent
   int mode = -1;
-  if (a.vec && !a.scale && !a.gate && !a.drop_mode && a.row_group == 0 && a.r_period == 0 &&
+  if (a.vec && !a.scale && (!a.gate || a.gate == RVIT_GATE_GELU_GRAD) && a.row_group == 0 && a.r_period == 0 &&
       (a.act == RVIT_ACT_NONE || a.act == RVIT_ACT_GELU) && (!a.R || a.r_f32)) {
     mode = (a.bias ? P8F_BIAS : 0) | (a.act == RVIT_ACT_GELU ? P8F_GELU : 0) | (a.C2 ? P8F_C2 : 0) | (a.R ? P8F_R32 : 0) |
-           (a.c_f32 ? P8F_CF32 : 0);
+           (a.c_f32 ? P8F_CF32 : 0) | (a.drop_mode == RVIT_DROP_PRE_RESIDUAL ? P8F_DROP_PRE : 0) |
+           (a.drop_mode == RVIT_DROP_POST_ACT ? P8F_DROP_POST : 0) | (a.gate ? P8F_GGELU : 0);
   }
 #ifdef P8_STAMPS
   // developer build: per-workgroup wall-clock / cycle stamps (start, prologue done, K loop done, end, inside the
@@ -473,9 +506,9 @@ int rvit_gemm8p(const GemmArgs& a, hipStream_t stream) {
   static unsigned long long* d_stamps = nullptr;
   if (!d_stamps) (void)hipMalloc(&d_stamps, 16 * 8 * 32768);
   (void)hipMemsetAsync(d_stamps, 0, 16 * 8 * 32768, stream);
-#define P8_LAUNCH(M_) hipLaunchKernelGGL(gemm8p_kernel<M_>, dim3((unsigned)tiles), dim3(512), P8_LDS, stream, a, d_stamps)
+#define P8_LAUNCH(M_) hipLaunchKernelGGL(gemm8p_kernel<M_>, dim3((unsigned)tiles), dim3(512), P8_LDS, stream, a, nt_store, d_stamps)
 #else
-#define P8_LAUNCH(M_) hipLaunchKernelGGL(gemm8p_kernel<M_>, dim3((unsigned)tiles), dim3(512), P8_LDS, stream, a)
+#define P8_LAUNCH(M_) hipLaunchKernelGGL(gemm8p_kernel<M_>, dim3((unsigned)tiles), dim3(512), P8_LDS, stream, a, nt_store)
 #endif
 #define P8_CASE(M_)                                                                          \
   case M_: {                                                                                 \
@@ -491,6 +524,10 @@ int rvit_gemm8p(const GemmArgs& a, hipStream_t stream) {
     P8_CASE(P8F_BIAS | P8F_GELU)                      // linear1 (inference)
     P8_CASE(P8F_BIAS | P8F_GELU | P8F_C2)             // linear1 (training, no dropout)
     P8_CASE(P8F_BIAS | P8F_R32 | P8F_CF32)            // out_proj / linear2: + fp32 residual stream
+    P8_CASE(P8F_BIAS | P8F_R32 | P8F_CF32 | P8F_DROP_PRE)        // ... training, dropout1 / dropout2
+    P8_CASE(P8F_BIAS | P8F_GELU | P8F_C2 | P8F_DROP_POST)        // linear1, training with dropout
+    P8_CASE(P8F_GGELU)                                           // input gradient through GELU (linear2^T)
+    P8_CASE(P8F_GGELU | P8F_DROP_POST)                           // ... with the dropout of the hidden map
     default: {
       static RvitLdsLimit lim;
       if (const int rc = lim.ensure({(const void*)gemm8p_kernel<-1>}, P8_LDS, "gemm8p")) return rc;

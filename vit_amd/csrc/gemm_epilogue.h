@@ -40,8 +40,7 @@ __device__ __forceinline__ void rvit_gemm_epilogue_row8(const GemmArgs& p, float
     }
     if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) {
       const uint32_t di = (uint32_t)(orow * p.N + n);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
+      drop_mult8(p.drop, di, v);   // vec form: N % 8 == 0 and n % 8 == 0, so di is even
     }
     if (p.R) {
       if (p.r_f32) {
@@ -67,8 +66,7 @@ __device__ __forceinline__ void rvit_gemm_epilogue_row8(const GemmArgs& p, float
     }
     if (p.drop_mode == RVIT_DROP_POST_ACT) {
       const uint32_t di = (uint32_t)(orow * p.N + n);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
+      drop_mult8(p.drop, di, v);   // vec form: N % 8 == 0 and n % 8 == 0, so di is even
     }
     if (p.c_f32) {
       float* cp = (float*)p.C + orow * p.ldc + n;
@@ -92,11 +90,11 @@ __device__ __forceinline__ void rvit_gemm_epilogue_row8(const GemmArgs& p, float
         x *= p.gate == RVIT_GATE_GELU_GRAD ? gelu_erf_grad(gv) : (gv > 0.f ? 1.f : 0.f);
       }
       if (p.C2) p.C2[orow * p.ldc2 + n + e] = (bf16)x;
-      if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) x *= drop_mult(p.drop, (uint32_t)(orow * p.N + n + e));
+      if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) x = rvit_mul_rn(x, drop_mult(p.drop, (uint32_t)(orow * p.N + n + e)));
       if (p.R) x += p.r_f32 ? ((const float*)p.R)[rrow * p.ldr + n + e]
                             : (float)((const bf16*)p.R)[rrow * p.ldr + n + e];
       x = rvit_apply_act(x, p.act);
-      if (p.drop_mode == RVIT_DROP_POST_ACT) x *= drop_mult(p.drop, (uint32_t)(orow * p.N + n + e));
+      if (p.drop_mode == RVIT_DROP_POST_ACT) x = rvit_mul_rn(x, drop_mult(p.drop, (uint32_t)(orow * p.N + n + e)));
       if (p.c_f32) ((float*)p.C)[orow * p.ldc + n + e] = x;
       else ((bf16*)p.C)[orow * p.ldc + n + e] = (bf16)x;
     }
@@ -176,8 +174,7 @@ __device__ __forceinline__ void rvit_epi_row_apply(const GemmArgs& p, float (&v)
   }
   if (p.drop_mode == RVIT_DROP_PRE_RESIDUAL) {
     const uint32_t di = (uint32_t)(orow * p.N + n);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
+    drop_mult8(p.drop, di, v);   // N % 8 == 0 and n % 8 == 0: di is even
   }
   if (p.R) {
     if (p.r_f32) {
@@ -202,8 +199,7 @@ __device__ __forceinline__ void rvit_epi_row_apply(const GemmArgs& p, float (&v)
   }
   if (p.drop_mode == RVIT_DROP_POST_ACT) {
     const uint32_t di = (uint32_t)(orow * p.N + n);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= drop_mult(p.drop, di + e);
+    drop_mult8(p.drop, di, v);   // N % 8 == 0 and n % 8 == 0: di is even
   }
   if (!store) return;
   if (p.c_f32) {
