@@ -34,7 +34,7 @@ def main():
         out = torch.empty_like(x)
         fl = 2.0 * B * hw * hw * c * c * 9
         for tile in tiles:
-            for with_res in (False,):
+            for with_res in (False, True):
                 kw = dict(scale=scale, bias=bias, act="relu", residual=res if with_res else None)
                 try:
                     us = bench(lambda: ops.conv2d(x, w, out, kh=3, kw=3, stride=1, pad=1, tile=tile, **kw))

@@ -100,20 +100,32 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
     const float4 a = *reinterpret_cast<const float4*>(p.bias + n), b = *reinterpret_cast<const float4*>(p.bias + n + 4);
     bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w;
   }
+  // The staging area is wave-private and a wave's LDS operations execute in order: no workgroup barrier between the
+  // passes (a __syncthreads() also waits vmcnt(0), i.e. for the previous pass's global stores to be acknowledged).
+  // vmcnt counts loads and stores in issue order, so a residual load issued after a store is not "back" before that
+  // store is: all residual rows of a restaging step are requested before its first store.
 #pragma unroll
   for (int i0 = 0; i0 < MR; i0 += EP_ROWS / 16) {
-  if (i0 > 0) __syncthreads();
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int i = 0; i < EP_ROWS / 16; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       *reinterpret_cast<f32x4*>(ep + (i * 16 + fr) * EP_PITCH + (j * 16 + fq * 4) * 4) = acc[i0 + i][j];
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();
+  uint4 rr[EP_ROWS / 8];
+  if (p.R) {
+#pragma unroll
+    for (int pass = 0; pass < EP_ROWS / 8; ++pass) {
+      long m = m0 + wm * WM + i0 * 16 + pass * 8 + er;
+      if (m > m_last) m = m_last;   // any valid row: not used
+      rr[pass] = *reinterpret_cast<const uint4*>((const bf16*)p.R + m * p.ldr + n);
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < EP_ROWS / 8; ++pass) {
     const int row = pass * 8 + er;
     const long m = m0 + wm * WM + i0 * 16 + row;
-    if (m > m_last) continue;
     float v[8];
     {
       const float4 lo = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4);
@@ -123,7 +135,7 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + bi[e];
     if (p.R) {
-      const uint4 r = *reinterpret_cast<const uint4*>((const bf16*)p.R + m * p.ldr + n);
+      const uint4 r = rr[pass];
       v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
       v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
     }
@@ -131,6 +143,7 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
+    if (m > m_last) continue;
     uint4 o;
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
     o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
