@@ -108,6 +108,49 @@ def test_gemm_mx_epilogue_and_mx_output(dev):
     assert torch.equal(oq2, oq) and torch.equal(os2, os_)
 
 
+@pytest.mark.parametrize("form", ["bias_bf16", "bias_res_f32", "bias_gelu_mx"])
+@pytest.mark.parametrize("M,N,K", [(33000, 1024, 1024), (20000, 2048, 256), (50432, 1024, 768 + 256)])
+def test_gemm_mx_eight_wave_kernel_bit_identical(dev, form, M, N, K):
+    """Products of >= 512 tiles of 256 x 256 with an encoder epilogue form run the eight-wave kernel (csrc/gemm_mx8p.hip);
+    row chunks of the same product small enough to stay on the 256 x 64 kernel (csrc/gemm_mx.hip) must give the same
+    bits: same K order, one block-scaled instruction per K tile.  Ragged M, scales of 2 .. 8 K tiles, the scale double
+    buffer crossing several groups of four K tiles; repeated launches (a DMA / read race shows as rare differing tiles)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))
+    w = torch.randn(N, K, generator=g) / math.sqrt(K) * torch.exp(torch.randn(1, K, generator=g) * 0.5)
+    bias = torch.randn(N, generator=g).to(dev)
+    aq, as_ = ops.quantize_mx(a.to(dev))
+    wq, ws = ops.quantize_mx(w.to(dev))
+    res = torch.randn(M, N, generator=g).to(dev) if form == "bias_res_f32" else None
+
+    def run(rows):
+        lo, hi = rows
+        n = hi - lo
+        aq_c = aq[lo:hi]
+        as_c = as_[lo // 16:(hi + 15) // 16].contiguous()
+        if form == "bias_gelu_mx":
+            oq = torch.empty(n, N, dtype=torch.uint8, device=dev)
+            osc = torch.zeros(ops.mx_scale_shape(n, N), dtype=torch.uint8, device=dev)
+            ops.gemm_mx(aq_c, as_c, wq, ws, None, bias=bias, act="gelu", out_q=oq, out_s=osc)
+            return oq, osc
+        out = torch.empty(n, N, device=dev, dtype=torch.float32 if form == "bias_res_f32" else torch.bfloat16)
+        ops.gemm_mx(aq_c, as_c, wq, ws, out, bias=bias, residual=None if res is None else res[lo:hi])
+        return (out,)
+    assert ((M + 255) // 256) * ((N + 255) // 256) >= 512
+    big = run((0, M))
+    step = 256 * (400 // ((N + 255) // 256))          # < 512 tiles per chunk, a multiple of 16 rows
+    for lo in range(0, M, step):
+        hi = min(M, lo + step)
+        small = run((lo, hi))
+        assert torch.equal(big[0][lo:hi], small[0]), (form, lo)
+        if form == "bias_gelu_mx":
+            assert torch.equal(big[1][lo // 16:(hi + 15) // 16], small[1]), (form, lo, "scales")
+    for _ in range(5):
+        again = run((0, M))
+        assert all(torch.equal(x, y) for x, y in zip(big, again))
+
+
 def test_gemm_mx_rejects_bad_shapes(dev):
     from vit_amd import ops
     from vit_amd._lib import RvitError

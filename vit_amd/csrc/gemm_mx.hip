@@ -312,6 +312,8 @@ int rvit_gemm_mxfp8_dispatch(const MxGemmArgs& a, hipStream_t st) {
     RVIT_CHECK_ARG(a.SCq && (a.N & 127) == 0 && a.ldcq >= a.N && (a.ldcq & 7) == 0 && ((uintptr_t)a.Cq & 7) == 0,
                    "gemm_mxfp8: MX output needs N %% 128 == 0, an 8-byte aligned value matrix and a scale matrix");
   if (a.M == 0) return RVIT_OK;
+  // large products with one of the encoder's epilogue forms: the eight-wave 256x256 kernel (gemm_mx8p.hip), same bits
+  if (const int mode = rvit_gemm_mx8p_mode(a); mode >= 0) return rvit_gemm_mx8p(a, mode, st);
   const long tiles = ((a.M + MX_BM - 1) / MX_BM) * (long)((a.N + MX_BN - 1) / MX_BN);
   RVIT_CHECK_ARG(tiles < 0x7fffffffL, "gemm_mxfp8: too many tiles");
   constexpr int lds = 2 * MX_TILE_BYTES;

@@ -96,6 +96,8 @@ int rvit_cast_bf16_impl(const float* x, bf16* out, long n, hipStream_t st);
 int rvit_transpose_batched_impl(const bf16* src, bf16* dst, const long* table, int n_entries, long total_tiles,
                                 hipStream_t st);
 int rvit_gemm_mxfp8_dispatch(const MxGemmArgs& a, hipStream_t st);
+int rvit_gemm_mx8p_mode(const MxGemmArgs& a);                  // gemm_mx8p.hip: -1 = not a case of the eight-wave kernel
+int rvit_gemm_mx8p(const MxGemmArgs& a, int mode, hipStream_t st);
 int rvit_quantize_mx_impl(const void* x, int x_f32, long ldx, uint8_t* q, long ldq, uint8_t* sc, long rows, int K,
                           hipStream_t st);
 
