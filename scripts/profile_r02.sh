@@ -22,3 +22,4 @@ run pmc_write --pmc WRITE_SIZE -- --no-cpu-baseline --no-train --steps 3 --warmu
 # MFMA pipe occupancy per kernel: 8 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)  (GUI_ACTIVE sums the 8 XCDs)
 run pmc_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- --no-cpu-baseline --no-train --steps 3 --warmup 1
 run pmc_mfma_vitb --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- --workload vitb-train --steps 2 --warmup 1
+run pmc_mfma_vitl --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- --workload vitl-infer-fp8 --steps 2 --warmup 1

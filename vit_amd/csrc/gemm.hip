@@ -351,7 +351,7 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   const bool big = big_plain || big_conv;
   int cfg;
   if (forced) cfg = forced;
-  else if (big_plain && rvit_gemm8p_ok(a)) cfg = 5;   // eight waves, four-phase K tile (gemm8p.hip): 0.92-1.13 vs 0.59-0.90 PFLOP/s on the ViT-B Linears, same bits
+  else if (a.mode == 0 && a.K >= 512 && t256 >= 512 && rvit_gemm8p_ok(a)) cfg = 5;   // eight waves, four-phase K tile (gemm8p.hip): 0.92-1.13 vs 0.59-0.90 PFLOP/s on the ViT-B Linears, same bits
   else if (big) cfg = 4;
   else if (((a.M + 255) / 256) * n64 >= 384) cfg = 1;
   else if (((a.M + 127) / 128) * n64 >= 256) cfg = 2;

@@ -583,6 +583,129 @@ def channel_scale(x: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     return x
 
 
+# ---- training pass of the MobileNetV3 stem (csrc/mobile_train.hip): every reduction ordered, workspace required ----
+
+def _ows_required(t: torch.Tensor, what: str):
+    ws, nb = _ows(t)
+    if ws is None:
+        raise RuntimeError(f"{what}: ordered reductions need ops.enable_ordered_reductions(device) first")
+    return ws, nb
+
+
+def _map2d(t: torch.Tensor, what: str):
+    if t.dtype != BF16 or not t.is_contiguous() or t.dim() < 2 or t.shape[-1] % 8:
+        raise ValueError(f"{what}: contiguous bf16 [..., C], C % 8 == 0")
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+def bn_generic_stats(y: torch.Tensor, sums: torch.Tensor) -> torch.Tensor:
+    """sums[0:C] += sum y, sums[C:2C] += sum y^2 over the rows of y bf16 [..., C] (any C % 8 == 0); ordered."""
+    _need_cuda(y, sums)
+    M, C = _map2d(y, "bn_generic_stats y")
+    _vec_f32(sums, 2 * C, "bn_generic_stats: sums")
+    ws, nb = _ows_required(y, "bn_generic_stats")
+    with _Span("bn_generic_stats", 0, _nbytes(y)):
+        check(_lib.load().rvit_bn_generic_stats(y.data_ptr(), M, C, sums.data_ptr(), ws, nb, _stream()), "rvit_bn_generic_stats")
+    return sums
+
+
+def bn_generic_apply(y: torch.Tensor, sums: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, z: torch.Tensor, *,
+                     eps: float, act: Optional[str] = None, residual: Optional[torch.Tensor] = None, momentum: float = 0.1,
+                     running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """z = act(gamma * (y - mean) / sqrt(var + eps) + beta + residual) with the batch statistics in `sums`; updates the
+    running statistics when given (train-mode nn.BatchNorm2d + timm's fused activation)."""
+    _need_cuda(y, sums, gamma, beta, z, residual, running_mean, running_var)
+    M, C = _map2d(y, "bn_generic_apply y")
+    if _map2d(z, "bn_generic_apply z") != (M, C) or (residual is not None and _map2d(residual, "bn_generic_apply residual") != (M, C)):
+        raise ValueError("bn_generic_apply: shape mismatch")
+    for v, n in ((sums, 2 * C), (gamma, C), (beta, C), (running_mean, C), (running_var, C)):
+        _vec_f32(v, n, "bn_generic_apply: per-channel operand")
+    with _Span("bn_generic_apply", 0, _nbytes(y, z, residual)):
+        check(_lib.load().rvit_bn_generic_apply(y.data_ptr(), sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(residual),
+                                                z.data_ptr(), M, C, float(eps), _ACT[act], float(momentum),
+                                                _ptr(running_mean), _ptr(running_var), _stream()), "rvit_bn_generic_apply")
+    return z
+
+
+def bn_generic_bwd(dz: torch.Tensor, y: torch.Tensor, fsums: torch.Tensor, bsums: torch.Tensor, gamma: torch.Tensor,
+                   beta: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, *, eps: float,
+                   act: Optional[str] = None) -> torch.Tensor:
+    """Backward of bn_generic_apply (activation included, recomputed from y): dy; dgamma += , dbeta += ; bsums (zeroed by
+    the caller) receives (sum g, sum g * xhat)."""
+    _need_cuda(dz, y, fsums, bsums, gamma, beta, dy, dgamma, dbeta)
+    M, C = _map2d(y, "bn_generic_bwd y")
+    if _map2d(dz, "bn_generic_bwd dz") != (M, C) or _map2d(dy, "bn_generic_bwd dy") != (M, C):
+        raise ValueError("bn_generic_bwd: shape mismatch")
+    for v, n in ((fsums, 2 * C), (bsums, 2 * C), (gamma, C), (beta, C), (dgamma, C), (dbeta, C)):
+        _vec_f32(v, n, "bn_generic_bwd: per-channel operand")
+    ws, nb = _ows_required(y, "bn_generic_bwd")
+    with _Span("bn_generic_bwd", 0, 2 * _nbytes(dz, y) + _nbytes(dy)):
+        check(_lib.load().rvit_bn_generic_bwd(dz.data_ptr(), y.data_ptr(), fsums.data_ptr(), bsums.data_ptr(), gamma.data_ptr(),
+                                              beta.data_ptr(), dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), M, C,
+                                              float(eps), _ACT[act], ws, nb, _stream()), "rvit_bn_generic_bwd")
+    return dy
+
+
+def _dw_geometry(x_shape, out_shape, k, stride, pad, what):
+    B, H, W, C = x_shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if tuple(out_shape) != (B, Ho, Wo, C) or C % 8:
+        raise ValueError(f"{what}: maps {tuple(x_shape)} / {tuple(out_shape)} do not match k={k} stride={stride} pad={pad}")
+    return B, H, W, C
+
+
+def dwconv_dgrad(dy: torch.Tensor, w: torch.Tensor, dx: torch.Tensor, *, k: int, stride: int, pad: int) -> torch.Tensor:
+    """Input gradient of ops.dwconv: dy bf16 [B,Ho,Wo,C], w bf16 [k*k, C] (the forward pack), dx bf16 [B,H,W,C]."""
+    _need_cuda(dy, w, dx)
+    B, H, W, C = _dw_geometry(dx.shape, dy.shape, k, stride, pad, "dwconv_dgrad")
+    if any(t.dtype != BF16 or not t.is_contiguous() for t in (dy, w, dx)) or tuple(w.shape) != (k * k, C):
+        raise ValueError("dwconv_dgrad: bf16 contiguous operands, w [k*k, C]")
+    with _Span("dwconv_dgrad", 2 * dx.numel() * k * k // (stride * stride), _nbytes(dy, dx)):
+        check(_lib.load().rvit_dwconv_dgrad_bf16(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, W, C, k, stride, pad,
+                                                 _stream()), "rvit_dwconv_dgrad_bf16")
+    return dx
+
+
+def dwconv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, k: int, stride: int, pad: int) -> torch.Tensor:
+    """dw f32 [C, k*k] (the parameter's [C,1,k,k] layout) += sum over pixels of dy * shifted x; ordered."""
+    _need_cuda(dy, x, dw)
+    B, H, W, C = _dw_geometry(x.shape, dy.shape, k, stride, pad, "dwconv_wgrad")
+    if dy.dtype != BF16 or x.dtype != BF16 or not (dy.is_contiguous() and x.is_contiguous()):
+        raise ValueError("dwconv_wgrad: bf16 contiguous maps")
+    _vec_f32(dw, C * k * k, "dwconv_wgrad: dw")
+    ws, nb = _ows_required(x, "dwconv_wgrad")
+    with _Span("dwconv_wgrad", 2 * dy.numel() * k * k, _nbytes(dy, x)):
+        check(_lib.load().rvit_dwconv_wgrad_bf16(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, C, k, stride, pad, ws, nb,
+                                                 _stream()), "rvit_dwconv_wgrad_bf16")
+    return dw
+
+
+def channel_affine(x: torch.Tensor, gate: torch.Tensor, out: torch.Tensor, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b,h,w,c] = x[b,h,w,c] * gate[b,c] (+ add[b,c]); bf16; out may be x."""
+    _need_cuda(x, gate, out, add)
+    B, H, W, C = x.shape
+    if any(t.dtype != BF16 or not t.is_contiguous() for t in (x, gate, out)) or out.shape != x.shape or tuple(gate.shape) != (B, C) \
+            or C % 8 or (add is not None and (add.dtype != BF16 or not add.is_contiguous() or tuple(add.shape) != (B, C))):
+        raise ValueError("channel_affine: x / out bf16 [B,H,W,C], gate / add bf16 [B,C], C % 8 == 0")
+    with _Span("channel_affine", 0, _nbytes(x, out)):
+        check(_lib.load().rvit_channel_affine_nhwc(x.data_ptr(), gate.data_ptr(), _ptr(add), out.data_ptr(), B, H * W, C, _stream()),
+              "rvit_channel_affine_nhwc")
+    return out
+
+
+def channel_dot(a: torch.Tensor, x: torch.Tensor, out: torch.Tensor, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b,c] = (sum over pixels of a * x) * hardsigmoid'(gate[b,c]) (gate = the hard-sigmoid OUTPUT; None: no factor)."""
+    _need_cuda(a, x, out, gate)
+    B, H, W, C = x.shape
+    if any(t.dtype != BF16 or not t.is_contiguous() for t in (a, x, out)) or a.shape != x.shape or tuple(out.shape) != (B, C) \
+            or C % 8 or (gate is not None and (gate.dtype != BF16 or not gate.is_contiguous() or tuple(gate.shape) != (B, C))):
+        raise ValueError("channel_dot: a / x bf16 [B,H,W,C], out / gate bf16 [B,C], C % 8 == 0")
+    with _Span("channel_dot", 2 * x.numel(), _nbytes(a, x)):
+        check(_lib.load().rvit_channel_dot_nhwc(a.data_ptr(), x.data_ptr(), _ptr(gate), out.data_ptr(), B, H * W, C, _stream()),
+              "rvit_channel_dot_nhwc")
+    return out
+
+
 SE_MAX_LDS_BYTES = 160 * 1024
 
 
