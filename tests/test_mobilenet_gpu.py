@@ -1,7 +1,7 @@
 """The reference's `backbone='mobilenetv3'` (timm mobilenetv3_small_100 features_only, train_vit.py:68-74,87): the
 HBM-bound kernels of csrc/mobile.hip against torch on the same bf16 operands, the new GEMM activations, and the whole
 classifier against the fp32 CPU oracle (oracle/ref_model.py::MobileNetV3SmallFeatures; parity at the timm boundary is
-unpinned, as for the resnet stems).  Inference only: train() forwards are refused."""
+unpinned, as for the resnet stems).  The training pass: tests/test_mobilenet_train_gpu.py, test_mobilenet_train_step_gpu.py."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -200,7 +200,7 @@ def test_mobilenetv3_model_matches_oracle(dev):
     assert want.std(0).mean().item() > 0.5 and len(set(want.argmax(1).tolist())) >= 3   # the logits depend on the input
 
 
-def test_mobilenetv3_checkpoint_round_trip_and_training_is_refused(dev, tmp_path):
+def test_mobilenetv3_checkpoint_round_trip(dev, tmp_path):
     from vit_amd.infer import load_model
     from vit_amd.synth import micro_doppler_batch, synth_checkpoint
     m, _ = _pair(dev)
@@ -213,9 +213,3 @@ def test_mobilenetv3_checkpoint_round_trip_and_training_is_refused(dev, tmp_path
     with torch.no_grad():
         assert torch.equal(m(x), m2(x))
     assert len(classes) == 11
-    m.train()
-    try:
-        with pytest.raises(NotImplementedError):
-            m(x)
-    finally:
-        m.eval()

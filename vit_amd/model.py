@@ -233,7 +233,7 @@ class CNNViTHybrid(nn.Module):
         "patch16": ("patch16", 3, 14),
     }
     _HIP_STEMS = ("resnet18", "resnet34", "patch16", "mobilenetv3")
-    _TRAIN_STEMS = ("resnet18", "resnet34", "patch16")   # the mobilenetv3 stem is built for inference only
+    _TRAIN_STEMS = ("resnet18", "resnet34", "patch16", "mobilenetv3")
 
     def __init__(self, num_classes, embed_dim=384, num_heads=6, num_layers=6, dropout=0.1,
                  pretrained_backbone=False, backbone="resnet34"):

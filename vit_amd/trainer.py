@@ -67,6 +67,8 @@ class _TorchPacker:
     def conv_bwd(self, n, tap_order=None): return _conv_bwd_pack(self.p[n], tap_order)
     def px4(self, n, kw_pad): return _px4_pack(self.p[n], kw_pad)
 
+    t_small = t   # (WeightMirror: transposes whose rows are not 8-element aligned, refreshed with a torch copy)
+
     def t_padded(self, n, mult):
         w = self.p[n].detach()
         out = torch.zeros(w.shape[1], mult * ((w.shape[0] + mult - 1) // mult), dtype=BF16, device=w.device)
@@ -142,6 +144,14 @@ class WeightMirror:
         out = torch.zeros(co, kh, kw_pad, 4, dtype=BF16, device=self._dev)
         self._small.append(lambda: out[:, :, :kw, :ci].copy_(src))
         return out.view(co, -1)
+
+    def t_small(self, n):
+        """[N, K] -> [K, N] for shapes the batched transpose cannot take (depthwise filters: K = 9 / 25)."""
+        off, numel, shape = self._seg(n)
+        src = self.bf16[off:off + numel].view(shape[0], -1)
+        out = torch.zeros(src.shape[1], src.shape[0], dtype=BF16, device=self._dev)
+        self._small.append(lambda: out.copy_(src.t()))
+        return out
 
     def t_padded(self, n, mult):
         off, numel, shape = self._seg(n)
@@ -237,6 +247,10 @@ class TrainEngine:
         # scratch workspace per device).  With both on, two runs of a step give the same bits in every gradient and
         # parameter.  RVIT_ORDERED=0 selects the float-atomic forms.
         self.ordered = os.environ.get("RVIT_ORDERED", "1") != "0"
+        self.mb = None   # MobileStemTrainer for backbone='mobilenetv3'
+        if getattr(model, "backbone_name", None) == "mobilenetv3":
+            from .mobile_trainer import MobileStemTrainer
+            self.mb = MobileStemTrainer(self)
 
     # ---- data parallel -------------------------------------------------------------------------
     def set_data_parallel(self, process_group=None, bucket_mb: float = 8.0) -> None:
@@ -271,7 +285,10 @@ class TrainEngine:
     def _build_pack(self, pk) -> dict:
         m = self.m
         P: dict = {}
-        if m.cnn_backbone is not None:
+        if self.mb is not None:
+            P["mb"] = self.mb.build_pack(pk)
+            P["pe_w"], P["pe_wt"] = pk.b("patch_embed.weight"), pk.t("patch_embed.weight")
+        elif m.cnn_backbone is not None:
             cb = m.cnn_backbone
             P["conv1_w"] = pk.px4("cnn_backbone.conv1.weight", 8)
             blocks = []
@@ -322,7 +339,10 @@ class TrainEngine:
         z = dict(dtype=BF16, device=dev)
         f = dict(dtype=F32, device=dev)
         b = {"dev": dev}
-        if m.cnn_backbone is not None:
+        if self.mb is not None:
+            b["mb"] = self.mb.buffers(B, dev)
+            b["scratch"] = {}
+        elif m.cnn_backbone is not None:
             b["img"] = torch.zeros(B, 230, 232, 4, **z)
             b["c1_y"] = torch.empty(B, 112, 112, 64, **z)
             # sign bits of the ReLU outputs (one byte per 8 channels): what the BatchNorm backward reads instead of z
@@ -457,8 +477,14 @@ class TrainEngine:
         xs = b["xs"]
         x0 = xs[0]
         if m.cnn_backbone is not None:
-            ops.input_pack(xin, b["img"], 3, 3)
-            feat = self._stem_forward(P, b, B)
+            if self.mb is not None:
+                if not self.ordered:
+                    raise RuntimeError("the mobilenetv3 training kernels only have ordered reductions (RVIT_ORDERED=0 is set)")
+                feat = self.mb.forward(P["mb"], b["mb"], B, xin)
+                torch._foreach_add_(self._bn_counters(), 1)
+            else:
+                ops.input_pack(xin, b["img"], 3, 3)
+                feat = self._stem_forward(P, b, B)
             b["feat"] = feat
             ops.gemm(feat.view(B * NP, -1), P["pe_w"], x0.view(T, E), bias=m.patch_embed.bias.detach(),
                      residual=m.pos_embed.detach().view(S, E)[1:], residual_period=NP, row_group=NP, row_extra=1,
@@ -666,7 +692,10 @@ class TrainEngine:
                 dfeat = self._scratch(b, ("dfeat",), feat)
                 ops.gemm(dxs_bf, P["pe_wt"], dfeat.view(B * NP, -1), a_rows=B * NP, a_row_group=NP, a_row_extra=1)
                 self._maybe_reduce(flat, "patch_embed.bias")
-                self._stem_backward(P, b, B, flat, dfeat)
+                if self.mb is not None:
+                    self.mb.backward(P["mb"], b["mb"], B, flat, dfeat)
+                else:
+                    self._stem_backward(P, b, B, flat, dfeat)
         else:
             dpatch = dxs_bf.view(B, S, E)[:, 1:].contiguous().view(B, 14, 14, E)
             dw = torch.zeros(E, 16 * 64, dtype=F32, device=dev)
