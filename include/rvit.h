@@ -71,9 +71,10 @@ const char* rvit_last_error(void);
  *   R: optional residual (bf16 or f32), row = m % r_period when r_period > 0, else the C row
  *   row remap (row_group, row_extra) applies to C, preact, gate and R
  *   drop_mode / drop_p / drop_seed: dropout in the epilogue (above); element index = C row * N + column
- *   tile: 0 = automatic tile choice, 1/2/3/4 force 256x64 / 128x64 / 64x64 / 256x256 (testing; the 256x256 tile of
- *   sixteen 64x64 waves is what large plain products run: K >= 512 and enough tiles for whole rounds of the chip;
- *   every tile contracts K in the same order, so the choice never changes a bit of the result). */
+ *   tile: 0 = automatic tile choice, 1/2/3/4 force 256x64 / 128x64 / 64x64 / 256x256 of sixteen 64x64 waves, 5 the
+ *   eight-wave 256x256 kernel with the four-phase K tile (csrc/gemm8p.hip: plain A operand, 16-byte aligned rows, K % 64
+ *   == 0; what products of >= 512 such tiles with K >= 512 run: the ViT-B / ViT-L Linears); for testing: every tile
+ *   contracts K in the same order, so the choice never changes a bit of the result. */
 int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int c_dtype, int64_t M, int N, int K, const float* scale, const float* bias,
                    const void* gate, int64_t ldg, int gate_mode, const void* R, int64_t ldr, int r_dtype,
