@@ -91,7 +91,7 @@ def test_attention_dropout_fwd_bwd(dev, S, H):
     ops.attention(qb, out, B, S, H, lse=lse, drop_p=p, drop_seed=seed)
     dqkv = torch.empty_like(qb)
     ops.attention_bwd(qb, out, db, lse, dqkv, B, S, H, drop_p=p, drop_seed=seed)
-    m = ops.dropout_mask(B * H * S * S, p, seed, dev).view(B, H, S, S).float() / (1 - p)
+    m = ops.attention_dropout_mask(B, H, S, p, seed, dev).float() / (1 - p)
     x = qb.float().requires_grad_(True)
     q, k, v = (u.view(B, S, H, 64).transpose(1, 2) for u in x.chunk(3, dim=-1))
     a = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) * m
@@ -120,6 +120,9 @@ def _replay_masks(m, ref, B, dev):
     masks = {}
     for site, shape in mask_shapes(ref, B).items():
         sid = {"pos": SITE_POS, "head": SITE_HEAD}[site] if isinstance(site, str) else _layer_site(site[0], which[site[1]])
+        if not isinstance(site, str) and site[1] == "attn":    # [B, H, S, S]: rows padded to an even stride
+            masks[site] = ops.attention_dropout_mask(shape[0], shape[1], shape[2], p, _site_seed(base, sid), dev).float().cpu()
+            continue
         n = 1
         for d in shape:
             n *= d

@@ -114,13 +114,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
         sum += pe;
       }
     sum += __shfl_xor(sum, 32, 64);
-    if (dk.thresh) {  // dropout on the (normalised) probabilities: element (pair, query, key)
-      const uint32_t base = (uint32_t)(((long)pair * S + query) * S);
+    if (dk.thresh) {
+      // dropout on the (normalised) probabilities.  Element index (pair * S + query) * S2 + key with the row stride
+      // S2 = S rounded up to even, so that keys (2j, 2j + 1) of a query always share one hash (common.h): a lane
+      // holds keys 4m .. 4m + 3 of its query, i.e. two whole hash pairs per group of four.
+      const uint32_t base2 = (uint32_t)(pair * S + query) * (uint32_t)((S + 1) >> 1);
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          sc[kb][r] *= drop_mult(dk, base + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2);
+        for (int g = 0; g < 4; ++g) {
+          float m[4];
+          drop_keep4(dk, base2 + kb * 16 + 4 * g + 2 * h2, dk.scale, m);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sc[kb][4 * g + e] *= m[e];
+        }
     }
 
     // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
@@ -417,7 +424,13 @@ __device__ __forceinline__ int du_off(int row, int ch) {
 // (NKB >= 5), so those cases run 8 waves (two per SIMD, one round over the <= 8 key / query blocks).
 template <int NKB> constexpr int bwd_waves() { return NKB >= 5 ? 8 : 4; }
 
-template <int NKB>
+// The element-wise work between the products is what bounds this kernel (rocprofv3 + ISA count, S = 197: ~490 vector
+// instructions per 32 x 32 block against 16 MFMAs; matrix pipe busy 0.12): dropout is a template parameter (no
+// per-element branches), the log-sum-exp arrives pre-multiplied by log2(e) and delta by the softmax scale (one fma each
+// at staging instead of one multiply per element), and the dropout hash is shared by the two keys of a pair (common.h):
+// in pass B a lane holds four consecutive keys of its query (two whole pairs); in pass A keys sit on the lanes, so lanes
+// 2j and 2j + 1 split the sixteen queries of a block between them and exchange the hashes by DPP (quad_perm).
+template <int NKB, bool DROP>
 __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
                                                        const bf16* __restrict__ dO, const float* __restrict__ lse,
                                                        bf16* __restrict__ dqkv, int total_pairs, int S, int H,
@@ -433,8 +446,10 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
   const int pair0 = blockIdx.x * PAIRS;
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   const float c_l2 = scale * 1.44269504088896340736f;
+  const uint32_t half_stride = (uint32_t)((S + 1) >> 1);   // dropout element index: (pair * S + query) * S2 + key, S2 even
+  const float keep_ds = dk.scale * scale;                  // multiplier of dP for a kept element, softmax scale folded in
 
-  // ---- stage Q, K, V, dO; delta = rowsum(dO * O); lse (padded queries: +inf -> P = 0) ------------
+  // ---- stage Q, K, V, dO; delta = rowsum(dO * O) * scale; lse * log2(e) (padded queries: +inf -> P = 0) ------------
 #pragma unroll
   for (int pi = 0; pi < PAIRS; ++pi) {
     const int pair = pair0 + pi;
@@ -469,8 +484,8 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
       d += __shfl_xor(d, 2, 64);
       d += __shfl_xor(d, 4, 64);
       if (c == 0) {
-        sDel[row] = d;
-        sLse[row] = ok ? lse[(long)pair * S + row] : INFINITY;
+        sDel[row] = d * scale;
+        sLse[row] = ok ? lse[(long)pair * S + row] * 1.44269504088896340736f : INFINITY;
       }
     }
   }
@@ -519,6 +534,25 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
       }
       // rows of the accumulators are queries qb*32 + 8g + 4h2 + (0..3)
+      uint32_t hq[DROP ? 16 : 1];
+      if constexpr (DROP) {
+        // this lane hashes 8 of the block's 16 accumulator rows (even key: rows 0-7, odd key: rows 8-15) for the key
+        // pair it belongs to; quad_perm [0,0,2,2] / [1,1,3,3] hands every lane the even / the odd lane's result
+        uint32_t mine[8];
+        const int odd = lane & 1;
+        const uint32_t kp = (uint32_t)(kb * 16 + (r32 >> 1));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int query = qb * 32 + (i & 3) + 8 * (i >> 2) + 16 * odd + 4 * h2;
+          mine[i] = rvit_drop_hash(dk, (uint32_t)(pair * S + query) * half_stride + kp);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          hq[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[i], 0xA0 /* quad_perm [0,0,2,2] */, 0xf, 0xf, false);
+          hq[i + 8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[i], 0xF5 /* quad_perm [1,1,3,3] */, 0xf, 0xf, false);
+        }
+      }
+      const int half_shift = 16 * (lane & 1);   // even key: low half of the pair's hash, odd key: high half
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 l4 = *reinterpret_cast<const float4*>(sLse + qb * 32 + 8 * g + 4 * h2);
@@ -528,14 +562,15 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float pe = __builtin_amdgcn_exp2f(sa[r] * c_l2 - lv[e] * 1.44269504088896340736f);
-          float mult = 1.f;
-          if (dk.thresh) {
-            const int query = qb * 32 + 8 * g + 4 * h2 + e;
-            mult = drop_mult(dk, (uint32_t)(((long)pair * S + query) * S + kb * 32 + r32));
+          const float pe = __builtin_amdgcn_exp2f(fmaf(sa[r], c_l2, -lv[e]));
+          if constexpr (DROP) {
+            const bool keep = ((hq[r] >> half_shift) & 0xffffu) >= dk.thresh;
+            sa[r] = pe * (keep ? dk.scale : 0.f);                         // dropped probabilities feed dV
+            dp[r] = pe * fmaf(dp[r], keep ? keep_ds : 0.f, -dl[e]);       // dS = P * (dP_drop * mask/(1-p) - delta) * scale
+          } else {
+            sa[r] = pe;
+            dp[r] = pe * fmaf(dp[r], scale, -dl[e]);
           }
-          sa[r] = pe * mult;                               // dropped probabilities feed dV
-          dp[r] = pe * (dp[r] * mult - dl[e]) * scale;     // dS = P * (dP_drop * mask/(1-p) - delta)
         }
       }
 #pragma unroll
@@ -594,8 +629,9 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
       qf[ks] = *reinterpret_cast<const bf16x8*>(sQ + du_off(qb * 32 + r32, ks * 2 + h2));
       df[ks] = *reinterpret_cast<const bf16x8*>(sD + du_off(qb * 32 + r32, ks * 2 + h2));
     }
-    const float lse_q = sLse[qb * 32 + r32] * 1.44269504088896340736f;
+    const float lse_q = sLse[qb * 32 + r32];
     const float del_q = sDel[qb * 32 + r32];
+    const uint32_t base2 = (uint32_t)(pair * S + qb * 32 + r32) * half_stride;
     f32x16 dQt[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -615,12 +651,18 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, df[ks], dpt, 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-        const float pe = key < S ? __builtin_amdgcn_exp2f(st[r] * c_l2 - lse_q) : 0.f;
-        float mult = 1.f;
-        if (dk.thresh) mult = drop_mult(dk, (uint32_t)(((long)pair * S + qb * 32 + r32) * S + key));
-        dpt[r] = pe * (dpt[r] * mult - del_q) * scale;
+      for (int g = 0; g < 4; ++g) {
+        // keys kb*32 + 8g + 4h2 + (0..3): two whole hash pairs
+        float m[4];
+        if constexpr (DROP) drop_keep4(dk, base2 + kb * 16 + 4 * g + 2 * h2, keep_ds, m);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          // padded keys (>= S) need no mask here: their K rows are zero in LDS, so whatever finite dS^T they get
+          // contributes K^T dS^T = 0 to dQ
+          const float pe = __builtin_amdgcn_exp2f(fmaf(st[r], c_l2, -lse_q));
+          dpt[r] = pe * fmaf(dpt[r], DROP ? m[e] : scale, -del_q);
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -653,19 +695,25 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
   }
 }
 
-template <int NKB>
-int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, bf16* dqkv, int B, int S, int H,
+template <int NKB, bool DROP>
+int launch_attn_bwd_t(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, bf16* dqkv, int B, int S, int H,
                     long ldq, long ldo, long lddo, long lddq, float scale, DropKey dk, hipStream_t st) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int LDS = PAIRS * (4 * 32 * NKB * 128 + 32 * NKB * 8);
   static RvitLdsLimit lim;
-  if (const int rc = lim.ensure({(const void*)attn_bwd_kernel<NKB>}, LDS, "attn_bwd")) return rc;
+  if (const int rc = lim.ensure({(const void*)attn_bwd_kernel<NKB, DROP>}, LDS, "attn_bwd")) return rc;
   const int total = B * H;
   const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
-  hipLaunchKernelGGL((attn_bwd_kernel<NKB>), dim3(grid), dim3(64 * bwd_waves<NKB>()), LDS, st, qkv, O, dO, lse, dqkv, total, S, H, ldq,
+  hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP>), dim3(grid), dim3(64 * bwd_waves<NKB>()), LDS, st, qkv, O, dO, lse, dqkv, total, S, H, ldq,
                      ldo, lddo, lddq, scale, dk);
   RVIT_CHECK_LAUNCH("attn_bwd");
   return RVIT_OK;
+}
+template <int NKB>
+int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, bf16* dqkv, int B, int S, int H,
+                    long ldq, long ldo, long lddo, long lddq, float scale, DropKey dk, hipStream_t st) {
+  return dk.thresh ? launch_attn_bwd_t<NKB, true>(qkv, O, dO, lse, dqkv, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st)
+                   : launch_attn_bwd_t<NKB, false>(qkv, O, dO, lse, dqkv, B, S, H, ldq, ldo, lddo, lddq, scale, dk, st);
 }
 
 }  // namespace
@@ -675,7 +723,7 @@ int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int
   RVIT_CHECK_ARG(qkv && out, "attn_fwd: null pointer");
   RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "attn_fwd: drop_p must be in [0, 1)");
   // the dropout element index is 32 bits wide; without dropout there is no such limit on the batch
-  RVIT_CHECK_ARG(drop_p == 0.f || (long)B * H * S * S < 0xffffffffL, "attn_fwd: dropout element index exceeds 32 bits");
+  RVIT_CHECK_ARG(drop_p == 0.f || (long)B * H * S * (S + (S & 1)) < 0xffffffffL, "attn_fwd: dropout element index exceeds 32 bits");
   const DropKey dk = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_fwd: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
   RVIT_CHECK_ARG(ldq >= 3L * H * 64 && (ldq & 7) == 0 && ldo >= (long)H * 64 && (ldo & 3) == 0,
@@ -702,7 +750,7 @@ int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const flo
                        hipStream_t st) {
   RVIT_CHECK_ARG(qkv && O && dO && lse && dqkv, "attn_bwd: null pointer");
   RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "attn_bwd: drop_p must be in [0, 1)");
-  RVIT_CHECK_ARG(drop_p == 0.f || (long)B * H * S * S < 0xffffffffL, "attn_bwd: dropout element index exceeds 32 bits");
+  RVIT_CHECK_ARG(drop_p == 0.f || (long)B * H * S * (S + (S & 1)) < 0xffffffffL, "attn_bwd: dropout element index exceeds 32 bits");
   const DropKey dk = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_bwd: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
   RVIT_CHECK_ARG(ldq >= 3L * H * 64 && lddq >= 3L * H * 64 && ldo >= (long)H * 64 && lddo >= (long)H * 64 &&

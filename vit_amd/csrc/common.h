@@ -152,10 +152,21 @@ __device__ __forceinline__ float rvit_apply_act(float x, int act) {
 // kept iff 16 bits of an integer hash of (key, idx >> 1) reach the threshold: one 32-bit hash decides TWO
 // neighbouring elements (its low half the even one, its high half the odd one).  Forward and backward
 // regenerate the same decision from (key, idx), no mask is stored.  Cost matters: the hash runs once per
-// output element in GEMM epilogues and on every attention probability, and 32-bit integer multiplies issue
-// at a quarter of the vector rate: the first form (two full rounds per ELEMENT, four multiplies) cost more
-// vector-ALU time in a ViT-B linear1 epilogue than the tile's whole K loop took on the matrix pipe; this one
-// is three multiplies per PAIR.  The drop probability is quantised to 1/65536 (p = 0.1 -> 0.100006).
+// output element in GEMM epilogues and on every attention probability (three times: forward and both backward
+// passes), and v_mul_lo_u32 issues at a QUARTER of the vector rate.  History: two full lowbias32 rounds per ELEMENT
+// (four multiplies) cost more vector-ALU time in a ViT-B linear1 epilogue than the tile's whole K loop took on the
+// matrix pipe; three 32-bit multiplies per PAIR still made the hash 59 % of the vector-ALU cycles of the attention
+// backward (rocprofv3 + ISA count: 48 v_mul_lo_u32 among 505 vector instructions per 32 x 32 block).  This form uses
+// only full-rate instructions: two rounds, each a pair of 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: the low
+// 24 bits of the word through one constant, bits 8..31 through another, so every input bit enters) and an
+// xor-shift; 12 instructions = 48 cycles per pair against 88.  Avalanche (flip one input bit, each output bit flips
+// with probability 0.488-0.525 over 2e5 inputs), drop rate, lag correlations of consecutive indices and seed
+// independence were checked against the previous hash before the switch (tests/test_dropout_gpu.py keeps the
+// statistical checks).  The drop probability is quantised to 1/65536 (p = 0.1 -> 0.100006).
+__device__ __forceinline__ uint32_t rvit_mix24(uint32_t x, uint32_t c_lo, uint32_t c_hi) {
+  return __umul24(x, c_lo) + __umul24(x >> 8, c_hi);
+}
+// full-width finaliser (lowbias32) for the places that hash once per sample, not per element (preproc.hip)
 __device__ __forceinline__ uint32_t rvit_mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
@@ -180,14 +191,23 @@ __device__ __forceinline__ float rvit_mul_rn(float a, float b) {
 }
 // 32 decision bits for the element pair (2 * pair, 2 * pair + 1)
 __device__ __forceinline__ uint32_t rvit_drop_hash(const DropKey& k, uint32_t pair) {
-  uint32_t h = rvit_mix32(pair + k.k0);
-  h = (h ^ k.k1) * 0x9E3779B1U;
-  return h ^ (h >> 15);
+  uint32_t h = rvit_mix24(pair + k.k0, 0xB5297Bu, 0x68E31Du);
+  h ^= h >> 15;
+  h = rvit_mix24(h ^ k.k1, 0x9E3779u, 0x7FEB35u);
+  return h ^ (h >> 16);
 }
 __device__ __forceinline__ float drop_mult(const DropKey& k, uint32_t idx) {
   const uint32_t h = rvit_drop_hash(k, idx >> 1);
   const uint32_t bits = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
   return bits >= k.thresh ? k.scale : 0.f;
+}
+// four consecutive elements starting at the EVEN index 2 * pair: two hashes; m[e] = `keep_value` or 0
+__device__ __forceinline__ void drop_keep4(const DropKey& k, uint32_t pair, float keep_value, float (&m)[4]) {
+  const uint32_t h0 = rvit_drop_hash(k, pair), h1 = rvit_drop_hash(k, pair + 1);
+  m[0] = (h0 & 0xffffu) >= k.thresh ? keep_value : 0.f;
+  m[1] = (h0 >> 16) >= k.thresh ? keep_value : 0.f;
+  m[2] = (h1 & 0xffffu) >= k.thresh ? keep_value : 0.f;
+  m[3] = (h1 >> 16) >= k.thresh ? keep_value : 0.f;
 }
 // eight consecutive elements starting at an EVEN index: four hashes
 __device__ __forceinline__ void drop_mult8(const DropKey& k, uint32_t idx0, float (&v)[8]) {

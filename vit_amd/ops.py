@@ -428,6 +428,14 @@ def dropout_mask(n: int, p: float, seed: int, device) -> torch.Tensor:
     return out
 
 
+def attention_dropout_mask(B: int, H: int, S: int, p: float, seed: int, device) -> torch.Tensor:
+    """uint8 [B, H, S, S]: keep mask of the attention-probability dropout site (p, seed).  The kernels index that site
+    as (pair * S + query) * S2 + key with the row stride S2 = S rounded up to even, so that keys (2j, 2j + 1) of a
+    query share one hash (csrc/attn.hip); this view drops the padding column (test/debug aid)."""
+    s2 = S + (S & 1)
+    return dropout_mask(B * H * S * s2, p, seed, device).view(B, H, S, s2)[..., :S]
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, eps: float = 1e-5,
               mean: Optional[torch.Tensor] = None, rstd: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Row LayerNorm; x [rows,E] (bf16/f32, row stride free), out [rows,E] (bf16/f32)."""
