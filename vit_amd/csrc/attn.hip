@@ -9,14 +9,42 @@
 // one cross-half shuffle; the exponentiated accumulator tile is fed straight back as the B
 // operand of the PV product (O^T = V^T P^T) with V^T fragments produced by the hardware
 // transposing LDS read.  The whole key range fits in registers (S <= 256), so no online rescale.
+#include <stdlib.h>
+
 #include "common.h"
 #include "rvit_internal.h"
 #include "mx_common.h"
 
 namespace {
 
-__device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-constexpr int V_PITCH = 192;  // bytes per V row in LDS
+// -DRVIT_ATTN_STAMPS (diagnosis builds only, scripts/attn_stamps.py): s_memtime of wave 0 at the phase boundaries of
+// the backward kernel, per workgroup
+#ifdef RVIT_ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[4096 * 8];
+#define ATTN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_attn_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTN_STAMP(k) do {} while (0)
+#endif
+
+// 16-byte-per-lane LDS-DMA (global_load_lds_dwordx4): lane l of the wave writes lds_wave_base + 16 l
+typedef __attribute__((address_space(3))) void attn_lds_void;
+typedef __attribute__((address_space(1))) const void attn_gbl_cvoid;
+__device__ __forceinline__ void attn_glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((attn_gbl_cvoid*)src, (attn_lds_void*)lds_wave_base, 16, 0, 0);
+}
+__device__ uint4 g_attn_zero[1];   // source of the rows past the sequence end
+
+// LDS image of a [rows][64] bf16 tensor that serves row reads (ds_read_b128) AND transposing reads (ds_read_b64_tr_b16)
+// conflict-free: 128-byte rows, 16-byte chunk index ^= bitreverse3((row >> 1) & 7).  attn_stage_rows fills 8 rows per
+// LDS-DMA instruction (lane-linear destination, so the swizzle goes on the source address); rows >= `rows_valid` read zeros.
+__device__ __forceinline__ int du_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+__device__ __forceinline__ int du_off(int row, int ch) { return row * 128 + ((ch ^ du_swz(row)) << 4); }
+__device__ __forceinline__ void attn_stage_rows(const bf16* src_row0, long ld, int rows_valid, char* image, int grp, int lane) {
+  const int row = grp * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ du_swz(row);
+  attn_glds16(row < rows_valid ? (const void*)(src_row0 + (long)row * ld + c * 8) : (const void*)g_attn_zero, image + grp * 1024);
+}
+
 
 __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -24,6 +52,29 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_bit_cast(bf16x4, r);
 }
 
+// One 64-column row per lane pair (lane, lane + 32): each lane holds 4 consecutive columns (8 bytes) of eight column
+// groups.  Stored as they are, that is sixteen 8-byte stores per lane and matrix, and the store tail of a workgroup is
+// bound by store ISSUE, not bandwidth (MI355X_MICROARCH.md, "attention epilogue store tail").  v_permlane32_swap
+// between the two lanes of a row pairs the groups up instead: lane h2 = 0 ends with columns 16j .. 16j + 7, lane
+// h2 = 1 with 16j + 8 .. 16j + 15: eight 16-byte stores.
+__device__ __forceinline__ void attn_store_row(bf16* row, const f32x16 (&acc)[2], int h2, float mul, bool ok) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      const int g0 = 2 * gp, g1 = 2 * gp + 1;
+      const uint32_t x0 = pack_bf16x2(acc[db][4 * g0 + 0] * mul, acc[db][4 * g0 + 1] * mul);
+      const uint32_t x1 = pack_bf16x2(acc[db][4 * g0 + 2] * mul, acc[db][4 * g0 + 3] * mul);
+      const uint32_t y0 = pack_bf16x2(acc[db][4 * g1 + 0] * mul, acc[db][4 * g1 + 1] * mul);
+      const uint32_t y1 = pack_bf16x2(acc[db][4 * g1 + 2] * mul, acc[db][4 * g1 + 3] * mul);
+      // upper lanes of x <-> lower lanes of y
+      const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+      const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+      uint4 w;
+      w.x = s0[0]; w.y = s1[0]; w.z = s0[1]; w.w = s1[1];
+      if (ok) *reinterpret_cast<uint4*>(row + db * 32 + 16 * gp + 8 * h2) = w;   // the swaps run on every lane
+    }
+}
 template <int NKB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int total_pairs, int S, int H,
@@ -31,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
                                                        DropKey dk) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int SP = 32 * NKB;
-  constexpr int PAIR_BYTES = SP * (128 + V_PITCH);
+  constexpr int PAIR_BYTES = SP * 256;   // K image, V image (du_off layout)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -45,17 +96,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     const int pair = pair0 + pi;
     const bool pv = pair < total_pairs;
     const int b = pv ? pair / H : 0, h = pv ? pair % H : 0;
+    // K and V by LDS-DMA (no register round trip, all 14 requests of a wave in flight): -12 % kernel time at S = 197
+    // against a loop of register loads + LDS stores
     const bf16* kbase = qkv + (long)b * S * ldq + E + h * 64;
-    const bf16* vbase = kbase + E;
     char* sK = smem + pi * PAIR_BYTES;
-    char* sV = sK + SP * 128;
-    for (int id = t; id < SP * 8; id += 256) {
-      const int row = id >> 3, c = id & 7;
-      const bool ok = pv && row < S;
-      const uint4 kv = ok ? *reinterpret_cast<const uint4*>(kbase + (long)row * ldq + c * 8) : zero4;
-      const uint4 vv = ok ? *reinterpret_cast<const uint4*>(vbase + (long)row * ldq + c * 8) : zero4;
-      *reinterpret_cast<uint4*>(sK + k_off(row, c)) = kv;
-      *reinterpret_cast<uint4*>(sV + row * V_PITCH + c * 16) = vv;
+    constexpr int GROUPS = SP / 8;
+    for (int gi = wave; gi < 2 * GROUPS; gi += 4) {   // wave-uniform
+      const int tensor = gi / GROUPS, grp = gi - tensor * GROUPS;
+      attn_stage_rows(kbase + tensor * E, ldq, pv ? S : 0, sK + tensor * SP * 128, grp, lane);
     }
   }
   __syncthreads();
@@ -88,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       for (int r = 0; r < 16; ++r) sc[kb][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + k_off(kb * 32 + r32, ks * 2 + h2));
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + du_off(kb * 32 + r32, ks * 2 + h2));
         sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
       }
     }
@@ -137,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     const int tr_q = (lane >> 2) & 3;
-    const int tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int tr_ch = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);  // + 4*db
+    const int tr_byte = (lane & 1) * 8;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
@@ -145,12 +194,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
         bf16x8 pb;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pb[j] = (bf16)sc[kb][8 * s + j];
-        const int key0 = kb * 32 + 16 * s + 4 * h2;
+        const int k0 = kb * 32 + 16 * s + 4 * h2 + tr_q;
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-          const char* base = sV + (key0 + tr_q) * V_PITCH + (db * 32 + tr_col) * 2;
-          const bf16x4 lo = tr_read(base);
-          const bf16x4 hi = tr_read(base + 8 * V_PITCH);
+          const bf16x4 lo = tr_read(sV + du_off(k0, 4 * db + tr_ch) + tr_byte);
+          const bf16x4 hi = tr_read(sV + du_off(k0 + 8, 4 * db + tr_ch) + tr_byte);
           bf16x8 vf;
           vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
           vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
@@ -159,19 +207,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       }
     }
     const float inv = 1.0f / sum;
-    if (q_ok) {
-      bf16* orow = out + ((long)b * S + query) * ldo + h * 64;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 w;
-          w.x = pack_bf16x2(o[db][4 * g + 0] * inv, o[db][4 * g + 1] * inv);
-          w.y = pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
-          *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g + 4 * h2) = w;
-        }
-      if (lse && h2 == 0) lse[(long)pair * S + query] = mx * scale + logf(sum);
-    }
+    attn_store_row(out + ((long)b * S + (q_ok ? query : 0)) * ldo + h * 64, o, h2, inv, q_ok);
+    if (q_ok && lse && h2 == 0) lse[(long)pair * S + query] = mx * scale + logf(sum);
   }
 }
 
@@ -179,7 +216,7 @@ template <int NKB>
 int launch_attn_fwd(const bf16* qkv, bf16* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
                     DropKey dk, hipStream_t st) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
-  constexpr int LDS = PAIRS * 32 * NKB * (128 + V_PITCH);
+  constexpr int LDS = PAIRS * 32 * NKB * 256;
   static RvitLdsLimit lim;
   if (const int rc = lim.ensure({(const void*)attn_fwd_kernel<NKB>}, LDS, "attn_fwd")) return rc;
   const int total = B * H;
@@ -415,14 +452,172 @@ int launch_attn_fwd_fp8(const bf16* qkv, uint8_t* out_q, uint8_t* out_s, int B, 
 //   pass B: a wave owns 32 queries (query on the lane), sweeps the key blocks:
 //           S^T, dP^T recomputed -> dS^T -> dQ^T += K^T dS^T
 // No cross-wave reduction and no atomics: dq, dk, dv are bitwise reproducible.
-__device__ __forceinline__ int du_off(int row, int ch) {
-  const int g = (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1);
-  return row * 128 + ((ch ^ g) << 4);
+
+// Operands that both sweeps of the backward share
+struct BwdCtx {
+  int pair, S;
+  uint32_t half_stride;   // dropout element index: (pair * S + query) * S2 + key, S2 = S rounded up to even
+  float c_l2, scale, keep_ds;
+  DropKey dk;
+};
+
+// pass A for the 32 keys a wave owns (K, V rows in registers): sweep the query blocks of the Q / dO images
+template <int NKB, bool DROP>
+__device__ __forceinline__ void bwd_sweep_queries(const char* sQ, const char* sD, const float* sLse, const float* sDel,
+                                                  const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int kb, const BwdCtx& cx,
+                                                  f32x16 (&dVt)[2], f32x16 (&dKt)[2]) {
+  const int lane = threadIdx.x & 63, r32 = lane & 31, h2 = lane >> 5;
+  const int tr_q = (lane >> 2) & 3;
+  const int tr_ch = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);  // + 4*db
+  const int tr_byte = (lane & 1) * 8;
+  const int pair = cx.pair, S = cx.S;
+  const uint32_t half_stride = cx.half_stride;
+  const float c_l2 = cx.c_l2, scale = cx.scale, keep_ds = cx.keep_ds;
+  const DropKey& dk = cx.dk;
+  (void)scale; (void)keep_ds; (void)half_stride; (void)pair;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dVt[db][r] = 0.f; dKt[db][r] = 0.f; }
+#pragma unroll 1
+  for (int qb = 0; qb < NKB; ++qb) {
+    if (qb * 32 >= S) break;
+    f32x16 sa, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + du_off(qb * 32 + r32, ks * 2 + h2));
+      const bf16x8 df = *reinterpret_cast<const bf16x8*>(sD + du_off(qb * 32 + r32, ks * 2 + h2));
+      sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sa, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+    }
+    // rows of the accumulators are queries qb*32 + 8g + 4h2 + (0..3)
+    uint32_t hq[DROP ? 16 : 1];
+    if constexpr (DROP) {
+      // this lane hashes 8 of the block's 16 accumulator rows (even key: rows 0-7, odd key: rows 8-15) for the key
+      // pair it belongs to; quad_perm [0,0,2,2] / [1,1,3,3] hands every lane the even / the odd lane's result
+      uint32_t mine[8];
+      const int odd = lane & 1;
+      const uint32_t kp = (uint32_t)(kb * 16 + (r32 >> 1));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int query = qb * 32 + (i & 3) + 8 * (i >> 2) + 16 * odd + 4 * h2;
+        mine[i] = rvit_drop_hash(dk, (uint32_t)(pair * S + query) * half_stride + kp);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        hq[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[i], 0xA0 /* quad_perm [0,0,2,2] */, 0xf, 0xf, false);
+        hq[i + 8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[i], 0xF5 /* quad_perm [1,1,3,3] */, 0xf, 0xf, false);
+      }
+    }
+    const int half_shift = 16 * (lane & 1);   // even key: low half of the pair's hash, odd key: high half
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 l4 = *reinterpret_cast<const float4*>(sLse + qb * 32 + 8 * g + 4 * h2);
+      const float4 d4 = *reinterpret_cast<const float4*>(sDel + qb * 32 + 8 * g + 4 * h2);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+      const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const float pe = __builtin_amdgcn_exp2f(fmaf(sa[r], c_l2, -lv[e]));
+        if constexpr (DROP) {
+          const bool keep = ((hq[r] >> half_shift) & 0xffffu) >= dk.thresh;
+          sa[r] = pe * (keep ? dk.scale : 0.f);                         // dropped probabilities feed dV
+          dp[r] = pe * fmaf(dp[r], keep ? keep_ds : 0.f, -dl[e]);       // dS = P * (dP_drop * mask/(1-p) - delta) * scale
+        } else {
+          sa[r] = pe;
+          dp[r] = pe * fmaf(dp[r], scale, -dl[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 pb, dsb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pb[j] = (bf16)sa[8 * s + j]; dsb[j] = (bf16)dp[8 * s + j]; }
+      const int q0 = qb * 32 + 16 * s + 4 * h2 + tr_q;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int o_lo = du_off(q0, 4 * db + tr_ch) + tr_byte;
+        const int o_hi = du_off(q0 + 8, 4 * db + tr_ch) + tr_byte;
+        const bf16x4 dlo = tr_read(sD + o_lo), dhi = tr_read(sD + o_hi);
+        const bf16x4 qlo = tr_read(sQ + o_lo), qhi = tr_read(sQ + o_hi);
+        const bf16x8 dOt = bf16x8{dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
+        const bf16x8 Qt = bf16x8{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+        dVt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOt, pb, dVt[db], 0, 0, 0);
+        dKt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt, dsb, dKt[db], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// pass B for the 32 queries a wave owns (Q, dO rows in registers): sweep the key blocks of the K / V images
+template <int NKB, bool DROP>
+__device__ __forceinline__ void bwd_sweep_keys(const char* sK, const char* sV, const bf16x8 (&qf)[4], const bf16x8 (&df)[4],
+                                               float lse_q, float del_q, int qb, const BwdCtx& cx, f32x16 (&dQt)[2]) {
+  const int lane = threadIdx.x & 63, r32 = lane & 31, h2 = lane >> 5;
+  const int tr_q = (lane >> 2) & 3;
+  const int tr_ch = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);  // + 4*db
+  const int tr_byte = (lane & 1) * 8;
+  const int S = cx.S;
+  const float c_l2 = cx.c_l2, scale = cx.scale, keep_ds = cx.keep_ds;
+  const DropKey& dk = cx.dk;
+  const uint32_t base2 = (uint32_t)(cx.pair * S + qb * 32 + r32) * cx.half_stride;
+  (void)scale; (void)keep_ds; (void)base2; (void)dk;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQt[db][r] = 0.f;
+#pragma unroll 1
+  for (int kb = 0; kb < NKB; ++kb) {
+    if (kb * 32 >= S) break;
+    f32x16 st, dpt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(sK + du_off(kb * 32 + r32, ks * 2 + h2));
+      const bf16x8 vfr = *reinterpret_cast<const bf16x8*>(sV + du_off(kb * 32 + r32, ks * 2 + h2));
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], st, 0, 0, 0);
+      dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, df[ks], dpt, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // keys kb*32 + 8g + 4h2 + (0..3): two whole hash pairs
+      float m[4];
+      if constexpr (DROP) drop_keep4(dk, base2 + kb * 16 + 4 * g + 2 * h2, keep_ds, m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        // padded keys (>= S) need no mask here: their K rows are zero in LDS, so whatever finite dS^T they get
+        // contributes K^T dS^T = 0 to dQ
+        const float pe = __builtin_amdgcn_exp2f(fmaf(st[r], c_l2, -lse_q));
+        dpt[r] = pe * fmaf(dpt[r], DROP ? m[e] : scale, -del_q);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 dsb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dsb[j] = (bf16)dpt[8 * s + j];
+      const int k0 = kb * 32 + 16 * s + 4 * h2 + tr_q;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const bf16x4 lo = tr_read(sK + du_off(k0, 4 * db + tr_ch) + tr_byte);
+        const bf16x4 hi = tr_read(sK + du_off(k0 + 8, 4 * db + tr_ch) + tr_byte);
+        const bf16x8 Kt = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        dQt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kt, dsb, dQt[db], 0, 0, 0);
+      }
+    }
+  }
 }
 
 // Waves per workgroup of the backward kernel: its four LDS images allow only one workgroup per CU once S > 128
 // (NKB >= 5), so those cases run 8 waves (two per SIMD, one round over the <= 8 key / query blocks).
 template <int NKB> constexpr int bwd_waves() { return NKB >= 5 ? 8 : 4; }
+template <int NKB> constexpr int bwd_image_bytes() { return (NKB >= 4 ? 1 : 4 / NKB) * (4 * 32 * NKB * 128 + 32 * NKB * 8); }
 
 // The element-wise work between the products is what bounds this kernel (rocprofv3 + ISA count, S = 197: ~490 vector
 // instructions per 32 x 32 block against 16 MFMAs; matrix pipe busy 0.12): dropout is a template parameter (no
@@ -440,6 +635,7 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
   constexpr int SP = 32 * NKB;
   constexpr int TILE = SP * 128;
   constexpr int PAIR_BYTES = 4 * TILE + SP * 8;
+
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int E = H * 64;
@@ -448,8 +644,16 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
   const float c_l2 = scale * 1.44269504088896340736f;
   const uint32_t half_stride = (uint32_t)((S + 1) >> 1);   // dropout element index: (pair * S + query) * S2 + key, S2 even
   const float keep_ds = dk.scale * scale;                  // multiplier of dP for a kept element, softmax scale folded in
+  ATTN_STAMP(0);
 
   // ---- stage Q, K, V, dO; delta = rowsum(dO * O) * scale; lse * log2(e) (padded queries: +inf -> P = 0) ------------
+  // This staging is 19k of the 42k cycles a workgroup lives at S = 197 (s_memtime stamps, scripts/attn_stamps.py):
+  // 126 KB per workgroup in 128-byte pieces 4.6 KB (qkv) / 1.5 KB (dO, O) apart, ~6 B per cycle and CU.  Measured
+  // alternatives, all on one box against this loop: every load of the workgroup requested before the first LDS store
+  // +9 % kernel time; the four images by LDS-DMA (attn_stage_rows, as the forward does) +2 %; two images at a time and
+  // four waves so that two workgroups share a CU (one staging while the other computes) +2 %; first-round workgroups
+  // started 3-20 us apart +1..5 %.  The forward, with half the bytes per workgroup and two workgroups per CU, does gain
+  // from the DMA form (-12 %).
 #pragma unroll
   for (int pi = 0; pi < PAIRS; ++pi) {
     const int pair = pair0 + pi;
@@ -489,12 +693,11 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
       }
     }
   }
+  ATTN_STAMP(1);
   __syncthreads();
+  ATTN_STAMP(2);
 
   const int r32 = lane & 31, h2 = lane >> 5;
-  const int tr_q = (lane >> 2) & 3;
-  const int tr_ch = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);  // + 4*db
-  const int tr_byte = (lane & 1) * 8;
 
   // ================================ pass A: dK, dV ================================================
   for (int ki = wave; ki < PAIRS * NKB; ki += bwd_waves<NKB>()) {
@@ -515,102 +718,19 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
       vf[ks] = *reinterpret_cast<const bf16x8*>(sV + du_off(kb * 32 + r32, ks * 2 + h2));
     }
     f32x16 dVt[2], dKt[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dVt[db][r] = 0.f; dKt[db][r] = 0.f; }
-
-#pragma unroll 1
-    for (int qb = 0; qb < NKB; ++qb) {
-      if (qb * 32 >= S) break;
-      f32x16 sa, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + du_off(qb * 32 + r32, ks * 2 + h2));
-        const bf16x8 df = *reinterpret_cast<const bf16x8*>(sD + du_off(qb * 32 + r32, ks * 2 + h2));
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sa, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
-      }
-      // rows of the accumulators are queries qb*32 + 8g + 4h2 + (0..3)
-      uint32_t hq[DROP ? 16 : 1];
-      if constexpr (DROP) {
-        // this lane hashes 8 of the block's 16 accumulator rows (even key: rows 0-7, odd key: rows 8-15) for the key
-        // pair it belongs to; quad_perm [0,0,2,2] / [1,1,3,3] hands every lane the even / the odd lane's result
-        uint32_t mine[8];
-        const int odd = lane & 1;
-        const uint32_t kp = (uint32_t)(kb * 16 + (r32 >> 1));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int query = qb * 32 + (i & 3) + 8 * (i >> 2) + 16 * odd + 4 * h2;
-          mine[i] = rvit_drop_hash(dk, (uint32_t)(pair * S + query) * half_stride + kp);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          hq[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[i], 0xA0 /* quad_perm [0,0,2,2] */, 0xf, 0xf, false);
-          hq[i + 8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[i], 0xF5 /* quad_perm [1,1,3,3] */, 0xf, 0xf, false);
-        }
-      }
-      const int half_shift = 16 * (lane & 1);   // even key: low half of the pair's hash, odd key: high half
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 l4 = *reinterpret_cast<const float4*>(sLse + qb * 32 + 8 * g + 4 * h2);
-        const float4 d4 = *reinterpret_cast<const float4*>(sDel + qb * 32 + 8 * g + 4 * h2);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
-        const float dl[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const float pe = __builtin_amdgcn_exp2f(fmaf(sa[r], c_l2, -lv[e]));
-          if constexpr (DROP) {
-            const bool keep = ((hq[r] >> half_shift) & 0xffffu) >= dk.thresh;
-            sa[r] = pe * (keep ? dk.scale : 0.f);                         // dropped probabilities feed dV
-            dp[r] = pe * fmaf(dp[r], keep ? keep_ds : 0.f, -dl[e]);       // dS = P * (dP_drop * mask/(1-p) - delta) * scale
-          } else {
-            sa[r] = pe;
-            dp[r] = pe * fmaf(dp[r], scale, -dl[e]);
-          }
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 pb, dsb;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { pb[j] = (bf16)sa[8 * s + j]; dsb[j] = (bf16)dp[8 * s + j]; }
-        const int q0 = qb * 32 + 16 * s + 4 * h2 + tr_q;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int o_lo = du_off(q0, 4 * db + tr_ch) + tr_byte;
-          const int o_hi = du_off(q0 + 8, 4 * db + tr_ch) + tr_byte;
-          const bf16x4 dlo = tr_read(sD + o_lo), dhi = tr_read(sD + o_hi);
-          const bf16x4 qlo = tr_read(sQ + o_lo), qhi = tr_read(sQ + o_hi);
-          const bf16x8 dOt = bf16x8{dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
-          const bf16x8 Qt = bf16x8{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
-          dVt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOt, pb, dVt[db], 0, 0, 0);
-          dKt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt, dsb, dKt[db], 0, 0, 0);
-        }
-      }
-    }
+    const BwdCtx cx{pair, S, half_stride, c_l2, scale, keep_ds, dk};
+    bwd_sweep_queries<NKB, DROP>(sQ, sD, sLse, sDel, kf, vf, kb, cx, dVt, dKt);
+    ATTN_STAMP(3);
+    // (Restaging the three outputs through a wave-private LDS area so that every store writes whole 128-byte rows was
+    // measured too: +5 % kernel time.  The swapped 16-byte stores are -1.5 % against 8-byte ones here, -5 % in the forward.)
     const int key = kb * 32 + r32;
-    if (key < S) {
-      bf16* krow = dqkv + ((long)b * S + key) * lddq + E + h * 64;
-      bf16* vrow = krow + E;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 w;
-          w.x = pack_bf16x2(dKt[db][4 * g + 0], dKt[db][4 * g + 1]);
-          w.y = pack_bf16x2(dKt[db][4 * g + 2], dKt[db][4 * g + 3]);
-          *reinterpret_cast<uint2*>(krow + db * 32 + 8 * g + 4 * h2) = w;
-          w.x = pack_bf16x2(dVt[db][4 * g + 0], dVt[db][4 * g + 1]);
-          w.y = pack_bf16x2(dVt[db][4 * g + 2], dVt[db][4 * g + 3]);
-          *reinterpret_cast<uint2*>(vrow + db * 32 + 8 * g + 4 * h2) = w;
-        }
-    }
+    const bool k_ok = key < S;
+    bf16* krow = dqkv + ((long)b * S + (k_ok ? key : 0)) * lddq + E + h * 64;
+    attn_store_row(krow, dKt, h2, 1.0f, k_ok);
+    attn_store_row(krow + E, dVt, h2, 1.0f, k_ok);
   }
 
+  ATTN_STAMP(4);
   // ================================ pass B: dQ =====================================================
   for (int qi = wave; qi < PAIRS * NKB; qi += bwd_waves<NKB>()) {
     const int pi = qi / NKB, qb = qi - pi * NKB;
@@ -631,78 +751,25 @@ __global__ __launch_bounds__(64 * bwd_waves<NKB>(), NKB >= 5 ? 2 : 1) void attn_
     }
     const float lse_q = sLse[qb * 32 + r32];
     const float del_q = sDel[qb * 32 + r32];
-    const uint32_t base2 = (uint32_t)(pair * S + qb * 32 + r32) * half_stride;
     f32x16 dQt[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dQt[db][r] = 0.f;
-#pragma unroll 1
-    for (int kb = 0; kb < NKB; ++kb) {
-      if (kb * 32 >= S) break;
-      f32x16 st, dpt;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(sK + du_off(kb * 32 + r32, ks * 2 + h2));
-        const bf16x8 vfr = *reinterpret_cast<const bf16x8*>(sV + du_off(kb * 32 + r32, ks * 2 + h2));
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[ks], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, df[ks], dpt, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // keys kb*32 + 8g + 4h2 + (0..3): two whole hash pairs
-        float m[4];
-        if constexpr (DROP) drop_keep4(dk, base2 + kb * 16 + 4 * g + 2 * h2, keep_ds, m);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          // padded keys (>= S) need no mask here: their K rows are zero in LDS, so whatever finite dS^T they get
-          // contributes K^T dS^T = 0 to dQ
-          const float pe = __builtin_amdgcn_exp2f(fmaf(st[r], c_l2, -lse_q));
-          dpt[r] = pe * fmaf(dpt[r], DROP ? m[e] : scale, -del_q);
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 dsb;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dsb[j] = (bf16)dpt[8 * s + j];
-        const int k0 = kb * 32 + 16 * s + 4 * h2 + tr_q;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const bf16x4 lo = tr_read(sK + du_off(k0, 4 * db + tr_ch) + tr_byte);
-          const bf16x4 hi = tr_read(sK + du_off(k0 + 8, 4 * db + tr_ch) + tr_byte);
-          const bf16x8 Kt = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          dQt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Kt, dsb, dQt[db], 0, 0, 0);
-        }
-      }
-    }
+    const BwdCtx cx{pair, S, half_stride, c_l2, scale, keep_ds, dk};
+    bwd_sweep_keys<NKB, DROP>(sK, sV, qf, df, lse_q, del_q, qb, cx, dQt);
+    ATTN_STAMP(5);
     const int query = qb * 32 + r32;
-    if (query < S) {
-      bf16* qrow = dqkv + ((long)b * S + query) * lddq + h * 64;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 w;
-          w.x = pack_bf16x2(dQt[db][4 * g + 0], dQt[db][4 * g + 1]);
-          w.y = pack_bf16x2(dQt[db][4 * g + 2], dQt[db][4 * g + 3]);
-          *reinterpret_cast<uint2*>(qrow + db * 32 + 8 * g + 4 * h2) = w;
-        }
-    }
+    const bool q_ok = query < S;
+    attn_store_row(dqkv + ((long)b * S + (q_ok ? query : 0)) * lddq + h * 64, dQt, h2, 1.0f, q_ok);
   }
+  ATTN_STAMP(6);
 }
 
 template <int NKB, bool DROP>
 int launch_attn_bwd_t(const bf16* qkv, const bf16* O, const bf16* dO, const float* lse, bf16* dqkv, int B, int S, int H,
                     long ldq, long ldo, long lddo, long lddq, float scale, DropKey dk, hipStream_t st) {
+  const int total = B * H;
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
-  constexpr int LDS = PAIRS * (4 * 32 * NKB * 128 + 32 * NKB * 8);
+  constexpr int LDS = bwd_image_bytes<NKB>();
   static RvitLdsLimit lim;
   if (const int rc = lim.ensure({(const void*)attn_bwd_kernel<NKB, DROP>}, LDS, "attn_bwd")) return rc;
-  const int total = B * H;
   const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
   hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP>), dim3(grid), dim3(64 * bwd_waves<NKB>()), LDS, st, qkv, O, dO, lse, dqkv, total, S, H, ldq,
                      ldo, lddo, lddq, scale, dk);
@@ -717,6 +784,12 @@ int launch_attn_bwd(const bf16* qkv, const bf16* O, const bf16* dO, const float*
 }
 
 }  // namespace
+
+#ifdef RVIT_ATTN_STAMPS
+extern "C" int rvit_debug_attn_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), (size_t)n * 8);
+}
+#endif
 
 int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
                        float drop_p, uint64_t drop_seed, hipStream_t st) {
