@@ -73,8 +73,16 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
 
   // workgroup -> (output tile, M split), tiles fastest.  (Pinning a split's tiles to one XCD so its L2
   // serves their re-reads was measured and is 5-15 % SLOWER on the stem shapes: profiles/r01_wgrad_splits.txt.)
-  const int tile_id = blockIdx.x % ntiles;
-  const int split = blockIdx.x / ntiles;
+  int bid = blockIdx.x;
+  if constexpr (W16) {
+    // XCD-aware id (as gemm.hip): the hardware deals workgroups to the 8 XCDs round-robin; remapped, the ~32 workgroups
+    // that share an XCD's L2 are consecutive tiles of (mostly) ONE M split, which read the same 64 rows of their common
+    // dY / X column blocks at the same time
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_id = bid % ntiles;
+  const int split = bid / ntiles;
   const int ntk = (p.K + TN - 1) / TN;
   const int tile_n = tile_id / ntk, tile_k = tile_id - tile_n * ntk;
   const int n0 = tile_n * TN, k0 = tile_k * TN;
