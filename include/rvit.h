@@ -328,7 +328,8 @@ int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx
  *   qkv: bf16 [B*S, ldq] holding q | k | v column blocks of width H*64 (the in-proj output);
  *   out: bf16 [B*S, ldo], head h at columns h*64..; lse (optional) fp32 [B,H,S].
  *   drop_p > 0: dropout on the normalised probabilities (functional.py:6569-6570), element index =
- *   ((b*H + h)*S + query)*S + key. */
+ *   ((b*H + h)*S + query)*S2 + key with the row stride S2 = S rounded up to even (keys 2j, 2j+1 of a query share
+ *   one hash of the generator; rvit_dropout_mask(n = B*H*S*S2) viewed [B,H,S,S2] replays the site). */
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
                   float drop_p, uint64_t drop_seed, void* stream);
 
