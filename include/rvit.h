@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 18
+#define RVIT_ABI_VERSION 19
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -322,6 +322,15 @@ int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx
                        const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
                        void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* workspace,
                        int64_t workspace_bytes, void* stream);
+/* rvit_layernorm_bwd whose bf16 copy additionally carries the dropout of the site that consumes it: dx_bf16 =
+ * bf16(dx) * mask(drop_p, drop_seed) / (1 - p), element index = row * E + col (the indexing of rvit_dropout_apply and of
+ * the GEMM epilogues).  In the pre-LN block the gradient that reaches out_proj / linear2 is the residual gradient
+ * times the mask of dropout1 / dropout2 (torch transformer.py:977,982), so the separate rvit_dropout_apply pass over
+ * that copy disappears; dx (fp32) is not masked.  drop_p = 0 is rvit_layernorm_bwd; drop_p > 0 needs dx_bf16. */
+int rvit_layernorm_bwd_drop(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                            const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
+                            void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E,
+                            void* workspace, int64_t workspace_bytes, float drop_p, uint64_t drop_seed, void* stream);
 
 /* softmax(q k^T * scale) v per (batch, head), head_dim 64, S <= 256, no mask
  * (torch functional.py:6623-6631 -> scaled_dot_product_attention).

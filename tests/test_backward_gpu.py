@@ -257,6 +257,22 @@ def test_layernorm_bwd(dev, rows, E, accumulate):
     _close(dxb, ref, 1.0 / 128, 1e-3, "ln dx bf16")
     _close(dg, gr.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln dgamma")
     _close(db, br.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln dbeta")
+    # rvit_layernorm_bwd_drop: the bf16 copy with the consuming site's dropout on it = rvit_dropout_apply on the plain
+    # copy, bit for bit; the fp32 gradient and the affine gradients are untouched
+    p_drop, seed = 0.25, 0x1234_5678_9ABC
+    dx2 = base.clone().to(dev)
+    dxb2 = torch.empty(rows, E, dtype=torch.bfloat16, device=dev)
+    dg2, db2 = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+    ops.layernorm_bwd(dy.to(dev), x.to(dev), mean.to(dev), rstd.to(dev), gam.to(dev), dx2, dg2, db2,
+                      accumulate=accumulate, dx_bf16=dxb2, drop=(p_drop, seed))
+    want = ops.dropout_apply(dxb, torch.empty_like(dxb), p_drop, seed)
+    assert torch.equal(dxb2, want), "fused dropout on the bf16 copy differs from rvit_dropout_apply"
+    assert torch.equal(dx2, dx)
+    kept = (dxb2 != 0).float().mean().item()
+    assert abs(kept - (1 - p_drop)) < 0.05, kept
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(dy.to(dev), x.to(dev), mean.to(dev), rstd.to(dev), gam.to(dev), dx2, dg2, db2,
+                          accumulate=accumulate, drop=(p_drop, seed))
 
 
 @pytest.mark.parametrize("B,S,H", [(3, 50, 4), (2, 197, 3), (4, 17, 2), (1, 64, 1), (2, 100, 2), (1, 256, 1)])

@@ -379,8 +379,16 @@ int rvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, int64_t ldx
                        void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E, void* workspace,
                        int64_t workspace_bytes, void* stream) {
   return rvit_layernorm_bwd_impl(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, accumulate, dx_bf16, lddb, dgamma,
-                                 dbeta, rows, E, (float*)workspace, workspace ? (size_t)workspace_bytes : 0,
+                                 dbeta, rows, E, (float*)workspace, workspace ? (size_t)workspace_bytes : 0, 0.f, 0,
                                  (hipStream_t)stream);
+}
+int rvit_layernorm_bwd_drop(const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                            const float* rstd, const float* gamma, float* dx, int64_t lddx, int accumulate,
+                            void* dx_bf16, int64_t lddb, float* dgamma, float* dbeta, int64_t rows, int E,
+                            void* workspace, int64_t workspace_bytes, float drop_p, uint64_t drop_seed, void* stream) {
+  return rvit_layernorm_bwd_impl(dy, lddy, x, ldx, mean, rstd, gamma, dx, lddx, accumulate, dx_bf16, lddb, dgamma,
+                                 dbeta, rows, E, (float*)workspace, workspace ? (size_t)workspace_bytes : 0, drop_p,
+                                 drop_seed, (hipStream_t)stream);
 }
 
 int rvit_attn_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,

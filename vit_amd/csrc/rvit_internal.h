@@ -144,7 +144,7 @@ int rvit_layernorm_mx_fwd_impl(const void* x, int x_f32, long ldx, const float* 
 int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                             const float* gamma, float* dxs, long lddx, int accumulate, void* dx_bf16, long lddb,
                             float* dgamma, float* dbeta, long rows, int E, float* ws, size_t ws_bytes,
-                            hipStream_t st);
+                            float drop_p, uint64_t drop_seed, hipStream_t st);
 int rvit_encoder_mlp_impl(float* x, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
                           const void* w2, const float* b2, long T, int E, int hidden, int rows_per_wg, hipStream_t st);
 int rvit_encoder_attn_impl(float* x, const float* gamma, const float* beta, float eps, const void* wqkv,

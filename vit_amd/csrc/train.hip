@@ -8,7 +8,10 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // LayerNorm backward, fused with the residual-gradient accumulation of the pre-LN block:
 //   dxs[row] (+)= rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
-// and an optional bf16 copy of the updated residual gradient (A operand of the next dgrad/wgrad).
+// and an optional bf16 copy of the updated residual gradient (A operand of the next dgrad/wgrad), optionally with the
+// dropout of the site that consumes it applied (the backward of dropout1 / dropout2, torch transformer.py:977,982: the
+// gradient that reaches out_proj / linear2 is the residual gradient times that site's mask; element index row * E +
+// col as rvit_dropout_apply, which this replaces: one pass of 155 MB read + 77 MB written per ViT-B site saved).
 // dgamma / dbeta are reduced per wave in registers over a grid-stride row loop, then across the
 // waves of the workgroup in LDS, and added with one global atomic per column per workgroup (at most
 // 256 workgroups: same-address atomics serialise in L2, 2M of them cost more than the whole pass).
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(THREADS) void layernorm_bwd_kernel(const bf16* __re
                                                             long lddx, int accumulate, bf16* __restrict__ dx_bf16,
                                                             long lddb, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, long rows, int E,
-                                                            float* __restrict__ ws) {
+                                                            float* __restrict__ ws, DropKey dk) {
   extern __shared__ float lnb_red[];  // [2 * IT * 256]; ordered mode (ws): one such vector per wave
   constexpr int WAVES = THREADS / 64;
   const int lane = threadIdx.x & 63;
@@ -85,6 +88,12 @@ __global__ __launch_bounds__(THREADS) void layernorm_bwd_kernel(const bf16* __re
         }
         *reinterpret_cast<float4*>(dp) = make_float4(o[0], o[1], o[2], o[3]);
         if (dx_bf16) {
+          if (dk.thresh) {   // e is a multiple of 4 and E is even: two whole hash pairs
+            float m[4];
+            drop_keep4(dk, (uint32_t)((row * E + e) >> 1), dk.scale, m);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = rvit_mul_rn((float)(bf16)o[k], m[k]);   // rounded first, as rvit_dropout_apply on the bf16 copy
+          }
           uint2 w;
           w.x = pack_bf16x2(o[0], o[1]);
           w.y = pack_bf16x2(o[2], o[3]);
@@ -256,8 +265,12 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict_
 int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                             const float* gamma, float* dxs, long lddx, int accumulate, void* dx_bf16, long lddb,
                             float* dgamma, float* dbeta, long rows, int E, float* ws, size_t ws_bytes,
-                            hipStream_t st) {
+                            float drop_p, uint64_t drop_seed, hipStream_t st) {
   RVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dxs && dgamma && dbeta, "layernorm_bwd: null pointer");
+  RVIT_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: drop_p must be in [0, 1)");
+  RVIT_CHECK_ARG(drop_p == 0.f || (dx_bf16 && rows * E < 0xffffffffL),
+                 "layernorm_bwd: the dropout applies to the bf16 copy (required) and indexes its elements in 32 bits");
+  const DropKey dk = make_drop_key(drop_p, drop_seed);
   RVIT_CHECK_ARG(E > 0 && (E & 3) == 0 && E <= LNB_MAX_IT * 256, "layernorm_bwd: E=%d unsupported", E);
   RVIT_CHECK_ARG((lddy & 3) == 0 && (ldx & 3) == 0 && (lddx & 3) == 0 && (!dx_bf16 || (lddb & 3) == 0),
                  "layernorm_bwd: pitches must be multiples of 4");
@@ -283,7 +296,7 @@ int rvit_layernorm_bwd_impl(const void* dy, long lddy, const float* x, long ldx,
     if (const int rc = lim.ensure({(const void*)layernorm_bwd_kernel<N, T>}, (int)lds, "layernorm_bwd")) return rc; \
     hipLaunchKernelGGL((layernorm_bwd_kernel<N, T>), dim3((unsigned)blocks), dim3(T), lds,                      \
                        st, (const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dxs, lddx, accumulate,             \
-                       (bf16*)dx_bf16, lddb, dgamma, dbeta, rows, E, ws);                                       \
+                       (bf16*)dx_bf16, lddb, dgamma, dbeta, rows, E, ws, dk);                                   \
     break;                                                                                                      \
   }
   switch (it) {

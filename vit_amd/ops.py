@@ -936,8 +936,9 @@ def conv1x1_dgrad_s2_acc(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor) 
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
                   dx: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, *, accumulate: bool,
-                  dx_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dx (+)= LN'(dy); dgamma/dbeta += ...; optional bf16 copy of the updated dx."""
+                  dx_bf16: Optional[torch.Tensor] = None, drop: Optional[Tuple[float, int]] = None) -> torch.Tensor:
+    """dx (+)= LN'(dy); dgamma/dbeta += ...; optional bf16 copy of the updated dx, with drop=(p, seed) multiplied by
+    that dropout site's mask / (1 - p) (element index row * E + col): what the next Linear's backward consumes."""
     _need_cuda(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, dx_bf16)
     rows, E, lddy = _rows2d(dy, "layernorm_bwd dy")
     rx, Ex, ldx = _rows2d(x, "layernorm_bwd x")
@@ -952,11 +953,15 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: t
             raise ValueError("layernorm_bwd: dx_bf16 mismatch")
     for v, n in ((mean, rows), (rstd, rows), (gamma, E), (dgamma, E), (dbeta, E)):
         _vec_f32(v, n, "layernorm_bwd: vector")
+    p_drop, seed = (float(drop[0]), int(drop[1])) if drop is not None else (0.0, 0)
+    if p_drop > 0.0 and dx_bf16 is None:
+        raise ValueError("layernorm_bwd: drop applies to the bf16 copy, which is missing")
     with _Span("layernorm_bwd", 0, rows * E * (2 + 4 + 8 + (2 if dx_bf16 is not None else 0))):
-        check(_lib.load().rvit_layernorm_bwd(dy.data_ptr(), lddy, x.data_ptr(), ldx, mean.data_ptr(), rstd.data_ptr(),
-                                             gamma.data_ptr(), dx.data_ptr(), lddx, int(accumulate), _ptr(dx_bf16),
-                                             lddb, dgamma.data_ptr(), dbeta.data_ptr(), rows, E, *_ows(dx), _stream()),
-              "rvit_layernorm_bwd")
+        check(_lib.load().rvit_layernorm_bwd_drop(dy.data_ptr(), lddy, x.data_ptr(), ldx, mean.data_ptr(), rstd.data_ptr(),
+                                                  gamma.data_ptr(), dx.data_ptr(), lddx, int(accumulate), _ptr(dx_bf16),
+                                                  lddb, dgamma.data_ptr(), dbeta.data_ptr(), rows, E, *_ows(dx), p_drop,
+                                                  seed, _stream()),
+              "rvit_layernorm_bwd_drop")
     return dx
 
 

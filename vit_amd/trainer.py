@@ -388,7 +388,6 @@ class TrainEngine:
         b["dxs"] = torch.empty(B, S, E, **f)
         b["dxs_bf"] = torch.empty(T, E, **z)
         b["d_e"] = torch.empty(T, E, **z)
-        b["d_e2"] = torch.empty(T, E, **z)
         b["d_3e"] = torch.empty(T, 3 * E, **z)
         b["d_4e"] = torch.empty(T, 4 * E, **z)
         b["d_h0"] = torch.empty(B, E // 2, **z)
@@ -642,6 +641,11 @@ class TrainEngine:
                           g("norm.bias"), accumulate=False, dx_bf16=dxb_cls)
         self._maybe_reduce(flat, "norm.bias")
         dx2 = dxs.view(T, E)
+        # The bf16 copy of the residual gradient leaves each LayerNorm backward already multiplied by the dropout mask of
+        # the site that consumes it (dropout2 of the layer below, dropout1 of this layer, pos_drop after layer 0):
+        # rvit_layernorm_bwd_drop.  Only the copy the final norm wrote (cls rows of a [B, S*E] view: another row
+        # numbering) still takes the separate pass.
+        masked = False
         for i in reversed(range(m.num_layers)):
             Lm, W = m.transformer.layers[i], P["layers"][i]
             p = f"transformer.layers.{i}."
@@ -649,7 +653,7 @@ class TrainEngine:
             st = b["stat"][i]
             # ---- MLP block:  xo = xm + fc2(gelu(fc1(LN2(xm))))
             dy = dxs_bf  # gradient of the block output; dropout2 masks what reaches linear2
-            if dp > 0.0:
+            if dp > 0.0 and not masked:
                 dy = ops.dropout_apply(dxs_bf, b["d_e"], dp, sd(_layer_site(i, SITE_FC2)))
             ops.linear_wgrad_bias(dy, b["h"][i], g2(p + "linear2.weight", E), g(p + "linear2.bias"))
             ops.gemm(dy, W["fc2_wt"], b["d_4e"], gate=b["u"][i], gate_mode="gelu_grad",
@@ -657,11 +661,10 @@ class TrainEngine:
             ops.linear_wgrad_bias(b["d_4e"], b["ln2"][i], g2(p + "linear1.weight", 4 * E), g(p + "linear1.bias"))
             ops.gemm(b["d_4e"], W["fc1_wt"], b["d_e"])
             ops.layernorm_bwd(b["d_e"], xm, st[2], st[3], Lm.norm2.weight.detach(), dx2, g(p + "norm2.weight"),
-                              g(p + "norm2.bias"), accumulate=True, dx_bf16=dxs_bf)
+                              g(p + "norm2.bias"), accumulate=True, dx_bf16=dxs_bf,
+                              drop=(dp, sd(_layer_site(i, SITE_PROJ))) if dp > 0.0 else None)
             # ---- attention block:  xm = xi + out_proj(attn(qkv(LN1(xi))))
-            dy = dxs_bf
-            if dp > 0.0:
-                dy = ops.dropout_apply(dxs_bf, b["d_e2"], dp, sd(_layer_site(i, SITE_PROJ)))
+            dy = dxs_bf   # dropout1's mask is on it already
             ops.linear_wgrad_bias(dy, b["att"][i], g2(p + "self_attn.out_proj.weight", E), g(p + "self_attn.out_proj.bias"))
             ops.gemm(dy, W["out_wt"], b["d_e"])
             ops.attention_bwd(b["qkv"][i], b["att"][i], b["d_e"], b["lse"][i], b["d_3e"], B, S, H, drop_p=dp,
@@ -669,12 +672,15 @@ class TrainEngine:
             ops.linear_wgrad_bias(b["d_3e"], b["ln1"][i], g2(p + "self_attn.in_proj_weight", 3 * E), g(p + "self_attn.in_proj_bias"))
             ops.gemm(b["d_3e"], W["qkv_wt"], b["d_e"])
             ops.layernorm_bwd(b["d_e"], xi, st[0], st[1], Lm.norm1.weight.detach(), dx2, g(p + "norm1.weight"),
-                              g(p + "norm1.bias"), accumulate=True, dx_bf16=dxs_bf)
+                              g(p + "norm1.bias"), accumulate=True, dx_bf16=dxs_bf,
+                              drop=(dp, sd(_layer_site(i - 1, SITE_FC2) if i > 0 else SITE_POS)) if dp > 0.0 else None)
+            masked = True
             self._maybe_reduce(flat, p + "norm1.bias")
         # ---- token assembly: x0 = pos_drop([cls + pos[0]; patch[b,p] + pos[1+p]])
         if dp > 0.0:
             ops.dropout_apply(dx2, dx2, dp, sd(SITE_POS))
-            ops.dropout_apply(dxs_bf, dxs_bf, dp, sd(SITE_POS))
+            if not masked:
+                ops.dropout_apply(dxs_bf, dxs_bf, dp, sd(SITE_POS))
         ops.batch_sum(dxs.view(B, S * E), g("pos_embed"))
         g("cls_token").copy_(g("pos_embed")[:E])
         limit = None
