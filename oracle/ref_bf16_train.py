@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .ref_model import CNNViTHybridRef, _BasicBlock
+from .ref_model import CNNViTHybridRef, MobileNetV3SmallFeatures, _BasicBlock, _MbBlockRef, _SqueezeExciteRef
 
 
 class _RoundSTE(torch.autograd.Function):
@@ -57,6 +57,16 @@ def emulate_hip_training_storage(ref: CNNViTHybridRef) -> None:
     cb = ref.cnn_backbone
     cb.register_forward_pre_hook(lambda m, i: (_RoundSTE.apply(i[0]),))
     rnd = lambda m, i, o: _RoundSTE.apply(o)  # noqa: E731
+    if isinstance(cb, MobileNetV3SmallFeatures):
+        # vit_amd/mobile_trainer.py keeps in bf16: every convolution output (depthwise, pointwise, conv_stem, the two
+        # squeeze-excite projections), every activated BatchNorm output, the gated map after a squeeze-excite and
+        # every block output (last BatchNorm + residual, rounded once); the BatchNorm pre-activations are recomputed
+        # in fp32 and never stored, so BatchNorm modules are not hooked by themselves.
+        for mod in cb.modules():
+            if isinstance(mod, (nn.Conv2d, nn.ReLU, nn.Hardswish, _SqueezeExciteRef, _MbBlockRef)):
+                mod.register_forward_hook(rnd)
+        cb.blocks[0].register_forward_pre_hook(lambda m, i: (_RoundSTE.apply(i[0]),))   # hardswish(bn1(conv_stem)) is functional
+        return
     cb.conv1.register_forward_hook(rnd)
     cb.bn1.register_forward_hook(rnd)
     for mod in cb.modules():

@@ -8,7 +8,12 @@ Stated bounds (fixed at about 1.5x what was measured when the test was written; 
 loss within 2 %; encoder / head / patch-embed gradients: relative L2 <= 8 %, cosine >= 0.995; stem gradients, whose
 BatchNorm + hard-swish / ReLU / hard-sigmoid chain amplifies bf16 storage of the 50 saved maps as the resnet stem's
 does (tests/test_train_gpu.py): cosine >= STEM_COS and relative L2 <= STEM_REL per tensor against the fp32 oracle;
-BatchNorm running statistics match; two runs of the step give the same bits (every reduction is ordered)."""
+BatchNorm running statistics match; two runs of the step give the same bits (every reduction is ordered).
+Where the stem distance comes from is measured in the test itself: the oracle with bf16 storage at the HIP path's storage
+points (oracle/ref_bf16_train.py) sits as far from the fp32 oracle as the HIP gradients do (median relative L2 0.18
+against 0.16), and the HIP gradients are as far from that emulation as from the fp32 oracle (two roundings of the same
+50 maps at different points of the arithmetic flip different hard-swish / ReLU / hard-sigmoid branches): bf16 map storage,
+not an arithmetic difference, sets these bounds, and a tighter per-tensor gate does not exist for this stem at B = 8."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -19,6 +24,8 @@ CFG = dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=2, dropout=0.0
 STEM_COS, STEM_REL = 0.90, 0.45
 ENC_REL = 0.08
 NULL_ABS = 4e-3
+EMU_FACTOR = 2.0
+EMU_REL, EMU_COS = 0.45, 0.90   # HIP stem gradients against the bf16-storage emulation of the oracle, per tensor
 
 
 def _pair(dev, seed=4):
@@ -76,6 +83,35 @@ def test_mobilenetv3_training_step_matches_autograd(dev):
     stem = [r for r in rows if r[2].startswith("cnn_backbone.")]
     print(f"   stem: worst rel {max(r[0] for r in stem):.4f} / {STEM_REL}, worst cos {min(r[1] for r in stem):.5f} / {STEM_COS}; "
           f"median rel {sorted(r[0] for r in stem)[len(stem) // 2]:.4f}")
+    # Sensitivity probe (not a pass / fail bound by itself): the same oracle with bf16 storage where the HIP path stores
+    # bf16 (oracle/ref_bf16_train.py) moves away from the fp32 oracle by about as much as the HIP gradients do - the
+    # distance above is what bf16 maps cost on this network, not an arithmetic difference.  Held loosely: the median
+    # stem distance of the HIP path stays within EMU_FACTOR x the emulation's.
+    from oracle.ref_bf16_train import emulate_hip_training_storage
+    from oracle.ref_model import CNNViTHybridRef
+    emu = CNNViTHybridRef(**CFG)
+    emu.load_state_dict({k: v.clone() for k, v in ref.state_dict().items()})
+    # (the step above updated the oracle's running statistics only: train-mode BatchNorm does not read them)
+    emulate_hip_training_storage(emu)
+    emu.train()
+    F.cross_entropy(emu(x), y, label_smoothing=0.05).backward()
+    erel, vs_emu = [], []
+    ghip = {n: p.grad.float().cpu() for n, p in m.named_parameters()}
+    for n, p in emu.named_parameters():
+        r = gref[n].grad
+        if n.startswith("cnn_backbone.") and r.norm().item() >= 1e-5 * gmax:
+            erel.append(((p.grad - r).norm() / r.norm()).item())
+            vs_emu.append((((ghip[n] - p.grad).norm() / p.grad.norm().clamp_min(1e-12)).item(),
+                           F.cosine_similarity(ghip[n].flatten(), p.grad.flatten(), dim=0).item(), n))
+    vs_emu.sort(reverse=True)
+    for rel, cos, n in vs_emu[:4]:
+        print(f"   vs bf16-storage oracle {n:45s} rel {rel:.4f} / {EMU_REL}  cos {cos:.5f} / {EMU_COS}")
+    assert all(rel <= EMU_REL and cos >= EMU_COS for rel, cos, _ in vs_emu), vs_emu[:4]
+    med_hip = sorted(r[0] for r in stem)[len(stem) // 2]
+    med_emu = sorted(erel)[len(erel) // 2]
+    print(f"   bf16-storage emulation of the oracle vs the fp32 oracle: stem median rel {med_emu:.4f}, worst {max(erel):.4f} "
+          f"(HIP: median {med_hip:.4f}, worst {max(r[0] for r in stem):.4f}); factor {med_hip / max(med_emu, 1e-9):.2f} / {EMU_FACTOR}")
+    assert med_hip <= EMU_FACTOR * med_emu, (med_hip, med_emu)
     null.sort(reverse=True)
     print(f"   {len(null)} tensors with a zero reference gradient: largest HIP norm / largest stem gradient norm "
           f"{null[0][0] if null else 0:.2e} ({null[0][1] if null else '-'}) / {NULL_ABS}")
