@@ -26,6 +26,35 @@ import torch.nn.functional as F
 from .ref_model import CNNViTHybridRef
 
 
+def keep_mask_numpy(n: int, p: float, seed: int):
+    """The counter-based generator of vit_amd/csrc/common.h (DropKey / rvit_drop_hash / drop_mult) restated in NumPy:
+    uint8 [n], 1 where element i of the site (p, seed) is kept.  One 32-bit hash per element PAIR (i >> 1) - two rounds
+    of {24-bit multiply of the low 24 bits + 24-bit multiply of bits 8..31, xor-shift} - whose low 16 bits decide the
+    even element and high 16 bits the odd one; kept iff those bits >= round(p * 2^16).  Integer arithmetic: the kernels'
+    masks (rvit_dropout_mask) must equal this bit for bit (tests/test_dropout_gpu.py).  The attention site indexes its
+    elements (pair * S + query) * S2 + key with S2 = S rounded up to even."""
+    import numpy as np
+    m32 = np.uint64(0xFFFFFFFF)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    thresh = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)) if p > 0 else 0
+    if thresh == 0:
+        return np.ones(n, dtype=np.uint8)
+
+    def mul24(a, c):
+        return ((a & np.uint64(0xFFFFFF)) * np.uint64(c)) & m32
+
+    def mix24(x, c_lo, c_hi):
+        return (mul24(x, c_lo) + mul24(x >> np.uint64(8), c_hi)) & m32
+
+    pair = np.arange((n + 1) // 2, dtype=np.uint64)
+    h = mix24((pair + k0) & m32, 0xB5297B, 0x68E31D)
+    h ^= h >> np.uint64(15)
+    h = mix24(h ^ k1, 0x9E3779, 0x7FEB35)
+    h ^= h >> np.uint64(16)
+    bits = np.stack([h & np.uint64(0xFFFF), h >> np.uint64(16)], axis=1).reshape(-1)[:n]
+    return (bits >= np.uint64(thresh)).astype(np.uint8)
+
+
 def mask_shapes(ref: CNNViTHybridRef, B: int) -> Dict[object, tuple]:
     """Site -> mask shape, in the element order the kernels index (row-major)."""
     E = ref.pos_embed.shape[-1]

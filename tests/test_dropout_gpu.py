@@ -37,6 +37,18 @@ def test_mask_statistics(dev):
         assert abs(m - (1 - pp)) < 5 * (pp * (1 - pp) / n) ** 0.5
 
 
+@pytest.mark.parametrize("n,p,seed", [(1 << 16, 0.1, 0x1234_5678_9ABC_DEF0), (12345, 0.3, 7), (2, 0.5, 0xFFFF_FFFF_FFFF_FFFF),
+                                      (1 << 20, 0.05, 0x0123_4567_0000_0001), (777, 0.9, 1 << 63)])
+def test_mask_equals_the_numpy_restatement(dev, n, p, seed):
+    """Integer work, bit-exact bar: the generator of csrc/common.h against oracle/ref_dropout.keep_mask_numpy."""
+    import numpy as np
+    from oracle.ref_dropout import keep_mask_numpy
+    from vit_amd import ops
+    got = ops.dropout_mask(n, p, seed, dev).cpu().numpy()
+    want = keep_mask_numpy(n, p, seed)
+    assert got.shape == want.shape and np.array_equal(got, want), f"{int((got != want).sum())} of {n} decisions differ"
+
+
 def test_dropout_apply_matches_mask(dev):
     from vit_amd import ops
     rows, cols, p, seed = 300, 256, 0.1, 991

@@ -210,3 +210,22 @@ def test_mobilenetv3_small_restatement_matches_the_published_size():
             "cnn_backbone.blocks.1.0.conv_pwl.weight", "cnn_backbone.blocks.4.2.bn3.running_var",
             "cnn_backbone.blocks.5.0.conv.weight"} <= keys
     assert "cnn_backbone.blocks.1.0.se.conv_reduce.weight" not in keys      # stage 1 has no squeeze-excite
+
+
+def test_dropout_generator_restatement():
+    """oracle/ref_dropout.keep_mask_numpy (the kernels' counter-based dropout generator restated in NumPy; the GPU
+    suite holds rvit_dropout_mask to it bit for bit): keep rate, determinism, one decision pair per 32-bit hash, and the
+    first decisions of one site as a regression vector."""
+    import numpy as np
+    from oracle.ref_dropout import keep_mask_numpy
+    n, p, seed = 1 << 20, 0.1, 0x1234_5678_9ABC_DEF0
+    m = keep_mask_numpy(n, p, seed)
+    assert m.dtype == np.uint8 and m.shape == (n,)
+    assert abs(m.mean() - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5
+    assert np.array_equal(m, keep_mask_numpy(n, p, seed))
+    assert list(m[:16]) == [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1]
+    assert np.array_equal(keep_mask_numpy(n - 1, p, seed), m[:-1])          # a prefix does not depend on n
+    assert keep_mask_numpy(1000, 0.0, seed).all()
+    other = keep_mask_numpy(n, p, seed ^ (1 << 40))
+    both = (m & other).mean()
+    assert abs(both - (1 - p) ** 2) < 6 * (p * (1 - p) / n) ** 0.5           # independent sites
