@@ -28,14 +28,19 @@ from .ref_model import CNNViTHybridRef
 
 def keep_mask_numpy(n: int, p: float, seed: int):
     """The counter-based generator of vit_amd/csrc/common.h (DropKey / rvit_drop_hash / drop_mult) restated in NumPy:
-    uint8 [n], 1 where element i of the site (p, seed) is kept.  One 32-bit hash per element PAIR (i >> 1) - two rounds
+    uint8 [n], 1 where element i of the site (p, seed) is kept.  The key (k0, k1) = halves of splitmix64(seed); one 32-bit hash per element PAIR (i >> 1) - two rounds
     of {24-bit multiply of the low 24 bits + 24-bit multiply of bits 8..31, xor-shift} - whose low 16 bits decide the
     even element and high 16 bits the odd one; kept iff those bits >= round(p * 2^16).  Integer arithmetic: the kernels'
     masks (rvit_dropout_mask) must equal this bit for bit (tests/test_dropout_gpu.py).  The attention site indexes its
     elements (pair * S + query) * S2 + key with S2 = S rounded up to even."""
     import numpy as np
     m32 = np.uint64(0xFFFFFFFF)
-    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    m64 = (1 << 64) - 1                      # key words: the halves of splitmix64(seed) (make_drop_key, on the host)
+    z = (seed + 0x9E3779B97F4A7C15) & m64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m64
+    z ^= z >> 31
+    k0, k1 = np.uint64(z & 0xFFFFFFFF), np.uint64(z >> 32)
     thresh = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5)) if p > 0 else 0
     if thresh == 0:
         return np.ones(n, dtype=np.uint8)

@@ -223,9 +223,9 @@ def test_dropout_generator_restatement():
     assert m.dtype == np.uint8 and m.shape == (n,)
     assert abs(m.mean() - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5
     assert np.array_equal(m, keep_mask_numpy(n, p, seed))
-    assert list(m[:16]) == [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1]
+    assert [int(v) for v in m[:16]] == [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1]
     assert np.array_equal(keep_mask_numpy(n - 1, p, seed), m[:-1])          # a prefix does not depend on n
     assert keep_mask_numpy(1000, 0.0, seed).all()
-    other = keep_mask_numpy(n, p, seed ^ (1 << 40))
-    both = (m & other).mean()
-    assert abs(both - (1 - p) ** 2) < 6 * (p * (1 - p) / n) ** 0.5           # independent sites
+    for delta in (1, 1 << 32, 1 << 40):      # related seeds (consecutive, one key word equal) still give independent sites
+        both = (m & keep_mask_numpy(n, p, seed ^ delta)).mean()
+        assert abs(both - (1 - p) ** 2) < 6 * (p * (1 - p) / n) ** 0.5, delta

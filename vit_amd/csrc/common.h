@@ -185,8 +185,16 @@ struct DropKey {
 };
 __host__ __device__ inline DropKey make_drop_key(float p, uint64_t seed) {
   DropKey k;
-  k.k0 = (uint32_t)seed;
-  k.k1 = (uint32_t)(seed >> 32);
+  // The two key words are the halves of splitmix64(seed), computed here on the host: the element hash adds k0 to the
+  // element index and xors k1 in between its two rounds, so RELATED keys would give related masks (seed + 1 as k0 is
+  // the same mask shifted by one pair; keys that differ only in k1 end in hashes a constant apart).  After this
+  // finaliser any two distinct seeds - consecutive integers included - give unrelated (k0, k1).
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  k.k0 = (uint32_t)z;
+  k.k1 = (uint32_t)(z >> 32);
   k.thresh = p > 0.f ? (uint32_t)(p * 65536.0f + 0.5f) : 0u;
   k.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   return k;
