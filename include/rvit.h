@@ -277,7 +277,10 @@ int rvit_dropout_apply(const void* in, void* out, int dtype, int64_t rows, int c
                        float p, uint64_t seed, void* stream);
 
 /* out[i] = 1 if element i of site (p, seed) is kept, else 0.  Test/debug aid: lets a host
- * reference replay the masks the kernels used. */
+ * reference replay the masks the kernels used.  The generator (every drop_seed of this header): key words = halves of
+ * splitmix64(seed), so any distinct seeds are independent sites; one 32-bit integer hash of (key, i >> 1) decides
+ * elements 2j and 2j + 1 (low / high 16 bits >= round(p * 2^16) keeps).  oracle/ref_dropout.py restates it in NumPy and
+ * this entry must equal it bit for bit. */
 int rvit_dropout_mask(uint8_t* out, int64_t n, float p, uint64_t seed, void* stream);
 
 /* LayerNorm over the last axis, eps inside the sqrt, affine (torch transformer.py:774,947-950;
