@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       attn_stage_rows(kbase + tensor * E, ldq, pv ? S : 0, sK + tensor * SP * 128, grp, lane);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed (explicit: not left to the fence of the barrier)
   __syncthreads();
 
   const int r32 = lane & 31, h2 = lane >> 5;
