@@ -21,9 +21,17 @@ namespace {
 // the backward kernel, per workgroup
 #ifdef RVIT_ATTN_STAMPS
 __device__ unsigned long long g_attn_stamps[4096 * 8];
-#define ATTN_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_attn_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATTN_PUT(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_attn_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef RVIT_ATTN_STAMPS_FWD   // the same array filled by the forward kernel instead (scripts/attn_fwd_stamps.py)
+#define ATTN_FSTAMP(k) ATTN_PUT(k)
+#define ATTN_STAMP(k) do {} while (0)
+#else
+#define ATTN_STAMP(k) ATTN_PUT(k)
+#define ATTN_FSTAMP(k) do {} while (0)
+#endif
 #else
 #define ATTN_STAMP(k) do {} while (0)
+#define ATTN_FSTAMP(k) do {} while (0)
 #endif
 
 // 16-byte-per-lane LDS-DMA (global_load_lds_dwordx4): lane l of the wave writes lds_wave_base + 16 l
@@ -106,8 +114,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       attn_stage_rows(kbase + tensor * E, ldq, pv ? S : 0, sK + tensor * SP * 128, grp, lane);
     }
   }
+  ATTN_FSTAMP(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA has landed (explicit: not left to the fence of the barrier)
   __syncthreads();
+  ATTN_FSTAMP(1);
 
   const int r32 = lane & 31, h2 = lane >> 5;
   for (int qi = wave; qi < PAIRS * NKB; qi += 4) {  // wave-uniform
@@ -129,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       qf[ks] = __builtin_bit_cast(bf16x8, u);
     }
 
+    if (qi == wave) ATTN_FSTAMP(2);
     // S^T[key][query] for all key blocks
     f32x16 sc[NKB];
 #pragma unroll
@@ -141,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
         sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
       }
     }
+    if (qi == wave) ATTN_FSTAMP(3);
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
@@ -179,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
         }
     }
 
+    if (qi == wave) ATTN_FSTAMP(4);
     // O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
     f32x16 o[2];
 #pragma unroll
@@ -207,10 +220,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
         }
       }
     }
+    if (qi == wave) ATTN_FSTAMP(5);
     const float inv = 1.0f / sum;
     attn_store_row(out + ((long)b * S + (q_ok ? query : 0)) * ldo + h * 64, o, h2, inv, q_ok);
     if (q_ok && lse && h2 == 0) lse[(long)pair * S + query] = mx * scale + logf(sum);
+    if (qi == wave) ATTN_FSTAMP(6);
   }
+  ATTN_FSTAMP(7);
 }
 
 template <int NKB>
