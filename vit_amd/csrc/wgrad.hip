@@ -18,6 +18,16 @@
 namespace {
 
 __device__ uint4 g_zero_page_w[4];
+// -DRVIT_WG_STAMPS (diagnosis builds only, scripts/wgrad_stamps.py): cycles wave 0 of a workgroup spends in the counted
+// wait, in the barrier and in the rest of the M loop of the sixteen-wave kernel
+#ifdef RVIT_WG_STAMPS
+__device__ unsigned long long g_wg_stamps[4096 * 4];
+#define WG_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define WG_ACC(dst, a, b) dst += (b) - (a)
+#else
+#define WG_T(v) do {} while (0)
+#define WG_ACC(dst, a, b) do {} while (0)
+#endif
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
@@ -187,9 +197,18 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
 
   ISSUE_MT(0, mt_begin);
   int stage = 0;
+#ifdef RVIT_WG_STAMPS
+  unsigned long long tw_vm = 0, tw_bar = 0, tw_all = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
   for (int it = 0; it < nmt; ++it) {
+    WG_T(t0_);
     wait_vmcnt<0>();
+    WG_T(t1_);
     __builtin_amdgcn_s_barrier();
+    WG_T(t2_);
+    WG_ACC(tw_vm, t0_, t1_);
+    WG_ACC(tw_bar, t1_, t2_);
     ISSUE_MT(stage ^ 1, mt_begin + it + 1);  // past mt_end: zero pages (keeps the protocol uniform)
     const char* sY = smem + stage * STAGE_B + (W16 ? (wn >> 1) * TILE_B : 0);
     const char* sX = smem + stage * STAGE_B + NSUB * TILE_B + (W16 ? (wk >> 1) * TILE_B : 0);
@@ -234,6 +253,15 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
     }
     stage ^= 1;
   }
+#ifdef RVIT_WG_STAMPS
+  tw_all = __builtin_amdgcn_s_memtime() - t_begin;
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    g_wg_stamps[blockIdx.x * 4 + 0] = tw_vm;
+    g_wg_stamps[blockIdx.x * 4 + 1] = tw_bar;
+    g_wg_stamps[blockIdx.x * 4 + 2] = tw_all;
+    g_wg_stamps[blockIdx.x * 4 + 3] = (unsigned long long)nmt;
+  }
+#endif
   wait_vmcnt<0>();
 #undef ISSUE_MT
   __builtin_amdgcn_s_barrier();
@@ -286,6 +314,12 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
 }
 
 }  // namespace
+
+#ifdef RVIT_WG_STAMPS
+extern "C" int rvit_debug_wgrad_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wg_stamps), (size_t)n * 8);
+}
+#endif
 
 // Ordered mode: carve the caller's workspace into `sub` slots per split for the weight tile partials (+ the bias sums),
 // limit the split count to what fits and make every split non-empty.
