@@ -2,7 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vit_amd import ops
+from vit_amd import _lib, ops
+if os.environ.get("RVIT_BENCH_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["RVIT_BENCH_LIB"])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 dev = torch.device("cuda:0")
 def timeit(fn, n=10):

@@ -45,6 +45,26 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
   return __builtin_bit_cast(bf16x4, r);
 }
+// Transposing fragment read issued as inline assembly, for loops that keep LDS-DMA in flight across their reads.  A DS
+// read the compiler can see makes its wait-count pass wait for EVERY LDS-DMA in flight (it cannot tell the ring stage
+// being filled from the one being read): in the sixteen-wave M loop that was an s_waitcnt vmcnt(0) between the request
+// of tile t+1 and the first fragment read of tile t - the whole L2 -> LDS latency exposed once per tile (rocprofv3: 53 %
+// of the wave cycles parked at a wait; s_memtime: wave 0 waited 2,050 of a tile's 4,922 cycles at the barrier for
+// waves still stuck there).  The workgroup barrier at the top of an iteration is what orders these reads after the DMA
+// that filled THEIR stage; tr_wait16 retires them (lgkmcnt) before the MFMAs that consume them.
+__device__ __forceinline__ void tr_read_asm(s16x4& dst, uint32_t lds_addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void tr_read_asm_1k(s16x4& dst, uint32_t lds_addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(dst) : "v"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void tr_wait16(s16x4 (&y)[8], s16x4 (&x)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]), "+v"(x[0]),
+                 "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+               :
+               : "memory");
+}
 // exact floor division for 0 <= m < 2^31, 0 < d < 2^15 via float reciprocal + one fix-up
 __device__ __forceinline__ int fdiv(int m, int d, float inv_d) {
   int q = (int)((float)m * inv_d);
@@ -195,6 +215,62 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
   const int rd_chunk_lo = pp >> 1;                                // + column-block chunk base
   const int rd_byte = (pp & 1) * 8;
 
+  if constexpr (W16) {
+    typedef __attribute__((address_space(3))) const char lds_cchar;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cchar*)smem;
+    ISSUE_MT(0, mt_begin);
+    for (int it = 0; it < nmt; ++it) {
+      const int stage = it & 1;
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      ISSUE_MT(stage ^ 1, mt_begin + it + 1);  // past mt_end: zero pages (keeps the protocol uniform)
+      const uint32_t aY = lds0 + stage * STAGE_B + (wn >> 1) * TILE_B;
+      const uint32_t aX = lds0 + stage * STAGE_B + NSUB * TILE_B + (wk >> 1) * TILE_B;
+      int fsw = f_r << 1;
+      asm volatile("" : "+v"(fsw));  // swizzled chunk offsets rebuilt per M tile: hoisted they spill at 128 VGPRs
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint32_t rbase = (uint32_t)((ks * 32 + rd_row) * 256 + rd_byte);
+        s16x4 yr[8], xr[8];   // [2 i] rows 0-3 of the 8-row group, [2 i + 1] rows 4-7
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t ch = (uint32_t)((((wn & 1) * 8 + i * 2 + rd_chunk_lo) ^ fsw) << 4);
+          tr_read_asm(yr[2 * i], aY + rbase + ch);
+          tr_read_asm_1k(yr[2 * i + 1], aY + rbase + ch);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t ch = (uint32_t)((((wk & 1) * 8 + j * 2 + rd_chunk_lo) ^ fsw) << 4);
+          tr_read_asm(xr[2 * j], aX + rbase + ch);
+          tr_read_asm_1k(xr[2 * j + 1], aX + rbase + ch);
+        }
+        tr_wait16(yr, xr);
+        bf16x8 yf[4], xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16x4 lo = __builtin_bit_cast(bf16x4, yr[2 * i]), hi = __builtin_bit_cast(bf16x4, yr[2 * i + 1]);
+          yf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const bf16x4 xl = __builtin_bit_cast(bf16x4, xr[2 * i]), xh = __builtin_bit_cast(bf16x4, xr[2 * i + 1]);
+          xf[i] = bf16x8{xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+        if (with_bias) {
+          int col = lane & 15;
+          asm volatile("" : "+v"(col));  // rebuilt per step: four hoisted selector tuples would not fit 128 VGPRs
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const short one = col == i ? (short)0x3f80 : (short)0;  // bf16 1.0
+            const s16x8 sel = s16x8{one, one, one, one, one, one, one, one};
+            bsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], __builtin_bit_cast(bf16x8, sel), bsum, 0, 0, 0);
+          }
+        }
+      }
+    }
+  } else {
   ISSUE_MT(0, mt_begin);
   int stage = 0;
 #ifdef RVIT_WG_STAMPS
@@ -262,6 +338,7 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
     g_wg_stamps[blockIdx.x * 4 + 3] = (unsigned long long)nmt;
   }
 #endif
+  }
   wait_vmcnt<0>();
 #undef ISSUE_MT
   __builtin_amdgcn_s_barrier();
