@@ -216,60 +216,95 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
   const int rd_byte = (pp & 1) * 8;
 
   if constexpr (W16) {
+    // Schedule of a 64-row tile t (two 32-row steps, fragments R0 / R1, MFMA groups M0 / M1), one barrier per tile:
+    //     wait R0(t) | M0(t) | R1(t), wait | wait DMA(t+1) | barrier | request DMA(t+2) | M1(t) | R0(t+1)
+    // The barrier sits between the arrival of R1 and M1, where this wave's M0 (and the other waves' MFMAs) are still
+    // executing, and the first reads of the next tile are issued behind M1 instead of behind the barrier: in the
+    // {barrier, R0, M0, R1, M1} order every wave of a SIMD waited out the LDS latency of R0 at the same time with an
+    // empty matrix pipe.  At the barrier every wave has all fragments of tile t in registers (its stage may be
+    // overwritten: DMA(t+2)) and has seen its share of DMA(t+1) land (the next tile may be read).
     typedef __attribute__((address_space(3))) const char lds_cchar;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cchar*)smem;
-    ISSUE_MT(0, mt_begin);
-    for (int it = 0; it < nmt; ++it) {
-      const int stage = it & 1;
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      ISSUE_MT(stage ^ 1, mt_begin + it + 1);  // past mt_end: zero pages (keeps the protocol uniform)
+    s16x4 yr[8], xr[8];   // [2 i] rows 0-3 of an 8-row group, [2 i + 1] rows 4-7
+    auto read_step = [&](int stage, int ks) {
       const uint32_t aY = lds0 + stage * STAGE_B + (wn >> 1) * TILE_B;
       const uint32_t aX = lds0 + stage * STAGE_B + NSUB * TILE_B + (wk >> 1) * TILE_B;
       int fsw = f_r << 1;
-      asm volatile("" : "+v"(fsw));  // swizzled chunk offsets rebuilt per M tile: hoisted they spill at 128 VGPRs
+      asm volatile("" : "+v"(fsw));  // swizzled chunk offsets rebuilt per step: hoisted they spill at 128 VGPRs
+      const uint32_t rbase = (uint32_t)((ks * 32 + rd_row) * 256 + rd_byte);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const uint32_t rbase = (uint32_t)((ks * 32 + rd_row) * 256 + rd_byte);
-        s16x4 yr[8], xr[8];   // [2 i] rows 0-3 of the 8-row group, [2 i + 1] rows 4-7
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t ch = (uint32_t)((((wn & 1) * 8 + i * 2 + rd_chunk_lo) ^ fsw) << 4);
+        tr_read_asm(yr[2 * i], aY + rbase + ch);
+        tr_read_asm_1k(yr[2 * i + 1], aY + rbase + ch);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t ch = (uint32_t)((((wk & 1) * 8 + j * 2 + rd_chunk_lo) ^ fsw) << 4);
+        tr_read_asm(xr[2 * j], aX + rbase + ch);
+        tr_read_asm_1k(xr[2 * j + 1], aX + rbase + ch);
+      }
+    };
+    auto mma_step = [&]() {
+      bf16x8 yf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4 lo = __builtin_bit_cast(bf16x4, yr[2 * i]), hi = __builtin_bit_cast(bf16x4, yr[2 * i + 1]);
+        yf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x4 xl = __builtin_bit_cast(bf16x4, xr[2 * i]), xh = __builtin_bit_cast(bf16x4, xr[2 * i + 1]);
+        xf[i] = bf16x8{xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
+      if (with_bias) {
+        int col = lane & 15;
+        asm volatile("" : "+v"(col));  // rebuilt per step: four hoisted selector tuples would not fit 128 VGPRs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const uint32_t ch = (uint32_t)((((wn & 1) * 8 + i * 2 + rd_chunk_lo) ^ fsw) << 4);
-          tr_read_asm(yr[2 * i], aY + rbase + ch);
-          tr_read_asm_1k(yr[2 * i + 1], aY + rbase + ch);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t ch = (uint32_t)((((wk & 1) * 8 + j * 2 + rd_chunk_lo) ^ fsw) << 4);
-          tr_read_asm(xr[2 * j], aX + rbase + ch);
-          tr_read_asm_1k(xr[2 * j + 1], aX + rbase + ch);
-        }
-        tr_wait16(yr, xr);
-        bf16x8 yf[4], xf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bf16x4 lo = __builtin_bit_cast(bf16x4, yr[2 * i]), hi = __builtin_bit_cast(bf16x4, yr[2 * i + 1]);
-          yf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          const bf16x4 xl = __builtin_bit_cast(bf16x4, xr[2 * i]), xh = __builtin_bit_cast(bf16x4, xr[2 * i + 1]);
-          xf[i] = bf16x8{xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], xf[j], acc[i][j], 0, 0, 0);
-        if (with_bias) {
-          int col = lane & 15;
-          asm volatile("" : "+v"(col));  // rebuilt per step: four hoisted selector tuples would not fit 128 VGPRs
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const short one = col == i ? (short)0x3f80 : (short)0;  // bf16 1.0
-            const s16x8 sel = s16x8{one, one, one, one, one, one, one, one};
-            bsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], __builtin_bit_cast(bf16x8, sel), bsum, 0, 0, 0);
-          }
+          const short one = col == i ? (short)0x3f80 : (short)0;  // bf16 1.0
+          const s16x8 sel = s16x8{one, one, one, one, one, one, one, one};
+          bsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[i], __builtin_bit_cast(bf16x8, sel), bsum, 0, 0, 0);
         }
       }
+    };
+    ISSUE_MT(0, mt_begin);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    ISSUE_MT(1, mt_begin + 1);
+    read_step(0, 0);
+#ifdef RVIT_WG_STAMPS
+    unsigned long long tw_vm = 0, tw_bar = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+    for (int it = 0; it < nmt; ++it) {
+      const int stage = it & 1;
+      tr_wait16(yr, xr);
+      mma_step();               // M0(it)
+      read_step(stage, 1);      // R1(it)
+      tr_wait16(yr, xr);
+      WG_T(t0_);
+      wait_vmcnt<0>();          // this thread's share of tile it + 1 has landed
+      WG_T(t1_);
+      __builtin_amdgcn_s_barrier();
+      WG_T(t2_);
+      WG_ACC(tw_vm, t0_, t1_);
+      WG_ACC(tw_bar, t1_, t2_);
+      ISSUE_MT(stage, mt_begin + it + 2);   // into the stage of tile it; past mt_end: zero pages (keeps the protocol uniform)
+      mma_step();               // M1(it)
+      read_step(stage ^ 1, 0);  // R0(it + 1); after the last tile: a stage of zero pages, never multiplied
     }
+    tr_wait16(yr, xr);
+#ifdef RVIT_WG_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+      g_wg_stamps[blockIdx.x * 4 + 0] = tw_vm;
+      g_wg_stamps[blockIdx.x * 4 + 1] = tw_bar;
+      g_wg_stamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memtime() - t_begin;
+      g_wg_stamps[blockIdx.x * 4 + 3] = (unsigned long long)nmt;
+    }
+#endif
   } else {
   ISSUE_MT(0, mt_begin);
   int stage = 0;
