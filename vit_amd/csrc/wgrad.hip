@@ -306,6 +306,8 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
     }
 #endif
   } else {
+  typedef __attribute__((address_space(3))) const char lds_cchar_g;
+  const uint32_t lds0g = (uint32_t)(uintptr_t)(lds_cchar_g*)smem;
   ISSUE_MT(0, mt_begin);
   int stage = 0;
 #ifdef RVIT_WG_STAMPS
@@ -321,28 +323,35 @@ __global__ __launch_bounds__(W16 ? 1024 : W8 ? 512 : 256, (W8 || W16) ? 4 : 2) v
     WG_ACC(tw_vm, t0_, t1_);
     WG_ACC(tw_bar, t1_, t2_);
     ISSUE_MT(stage ^ 1, mt_begin + it + 1);  // past mt_end: zero pages (keeps the protocol uniform)
-    const char* sY = smem + stage * STAGE_B + (W16 ? (wn >> 1) * TILE_B : 0);
-    const char* sX = smem + stage * STAGE_B + NSUB * TILE_B + (W16 ? (wk >> 1) * TILE_B : 0);
-    int fsw = f_r << 1;
-    if constexpr (W16) asm volatile("" : "+v"(fsw));  // swizzled chunk offsets rebuilt per M tile: hoisted they spill at 128 VGPRs
+    // (this branch: the 128 x 128 variants; fragment reads as inline assembly for the reason given at tr_read_asm)
+    const uint32_t aY = lds0g + stage * STAGE_B;
+    const uint32_t aX = lds0g + stage * STAGE_B + NSUB * TILE_B;
+    const int fsw = f_r << 1;
 #pragma unroll
     for (int ks0 = 0; ks0 < ((NARROW || W8) ? 1 : 2); ++ks0) {
       const int ks = NARROW ? (wave >> 1) : W8 ? (wave >> 2) : ks0;
-      bf16x8 yf[4], xf[4];
-      const int rbase = (ks * 32 + rd_row) * 256 + rd_byte;
+      s16x4 yr[8], xr[8];
+      const uint32_t rbase = (uint32_t)((ks * 32 + rd_row) * 256 + rd_byte);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int ch = (((W16 ? (wn & 1) : wn) * 8 + i * 2 + rd_chunk_lo) ^ fsw) << 4;
-        const bf16x4 lo = tr_read(sY + rbase + ch);
-        const bf16x4 hi = tr_read(sY + rbase + 4 * 256 + ch);
-        yf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const uint32_t ch = (uint32_t)(((wn * 8 + i * 2 + rd_chunk_lo) ^ fsw) << 4);
+        tr_read_asm(yr[2 * i], aY + rbase + ch);
+        tr_read_asm_1k(yr[2 * i + 1], aY + rbase + ch);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ch = (((W16 ? (wk & 1) : wk) * 8 + j * 2 + rd_chunk_lo) ^ fsw) << 4;
-        const bf16x4 lo = tr_read(sX + rbase + ch);
-        const bf16x4 hi = tr_read(sX + rbase + 4 * 256 + ch);
-        xf[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const uint32_t ch = (uint32_t)(((wk * 8 + j * 2 + rd_chunk_lo) ^ fsw) << 4);
+        tr_read_asm(xr[2 * j], aX + rbase + ch);
+        tr_read_asm_1k(xr[2 * j + 1], aX + rbase + ch);
+      }
+      tr_wait16(yr, xr);
+      bf16x8 yf[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bf16x4 lo = __builtin_bit_cast(bf16x4, yr[2 * i]), hi = __builtin_bit_cast(bf16x4, yr[2 * i + 1]);
+        yf[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x4 xl = __builtin_bit_cast(bf16x4, xr[2 * i]), xh = __builtin_bit_cast(bf16x4, xr[2 * i + 1]);
+        xf[i] = bf16x8{xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
