@@ -97,6 +97,12 @@ FITTED = {
     "P": (dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.0, backbone="patch16"), 5),
 }
 HEAD_KEYS = ("head.0.weight", "head.0.bias", "head.3.weight", "head.3.bias")
+# large-width fixtures (python scripts/make_golden.py fitted_big): BASELINE configs[3] / configs[4] at their own size.
+# Only head.3 (11 x E/2 weights + 11 biases, ~20 KB) is fitted and committed; head.0 stays synthetic.
+FITTED_BIG = {
+    "B": (dict(num_classes=11, embed_dim=768, num_heads=12, num_layers=12, dropout=0.0, backbone="patch16"), 8),
+    "L": (dict(num_classes=11, embed_dim=1024, num_heads=16, num_layers=24, dropout=0.0, backbone="patch16"), 9),
+}
 
 
 def make_fitted(name):
@@ -144,9 +150,64 @@ def make_fitted(name):
     assert out["fit_logits"].argmax(1).tolist() == [j % 11 for j in range(33)]
 
 
+def make_fitted_big(name):
+    """ViT-B/16- and ViT-L/16-scale fixtures (E768/H12/L12, E1024/H16/L24): the last head Linear is fitted on the
+    oracle's fp32 cls features AND on the features of the CPU MX-fp8 emulation (oracle/ref_mxfp8.py), both with added
+    noise of the size of the fp8 format's feature error (rms 0.1 per element, measured: 0.09-0.10), so that the fp32
+    oracle's labels (image i -> class i, frame j -> class j % 11) have margins that survive either precision.  The
+    vectors hold the fp32 oracle's logits (the parity target) and the emulation's (the format's cost, for the record)."""
+    from oracle.ref_mxfp8 import forward_mxfp8_emulated
+    torch.set_num_threads(8)
+    cfg, seed = FITTED_BIG[name]
+    ref = CNNViTHybridRef(**cfg)
+    sd = synth_state_dict({k: v.shape for k, v in ref.state_dict().items()}, seed)
+    ref.load_state_dict(sd)
+    ref.eval()
+    ximg = torch.stack([preprocess(Image.open(os.path.join(GOLD, "images", c + ".png"))) for c in CLASSES])
+    xfit = micro_doppler_batch(33, seed=4242)
+    xheld = micro_doppler_batch(16, seed=777)
+    xs = torch.cat([ximg, xfit, xheld])
+    y = torch.cat([torch.arange(11), torch.arange(33) % 11])
+    with torch.no_grad():
+        f = ref.forward_features(xs)
+        fe = forward_mxfp8_emulated(ref, xs, features_only=True)
+    W0, b0 = sd["head.0.weight"], sd["head.0.bias"]
+    hid = lambda u: F.gelu(F.linear(u, W0, b0))   # noqa: E731  (train_vit.py:122-124)
+    torch.manual_seed(0)
+    W3 = torch.zeros(11, cfg["embed_dim"] // 2, requires_grad=True)
+    b3 = torch.zeros(11, requires_grad=True)
+    opt = torch.optim.AdamW([W3, b3], lr=1e-2, weight_decay=0.05)
+    for _ in range(800):
+        opt.zero_grad()
+        u = torch.cat([f[:44] + 0.1 * torch.randn(44, f.shape[1]), fe[:44] + 0.1 * torch.randn(44, f.shape[1])])
+        F.cross_entropy(F.linear(hid(u), W3, b3), torch.cat([y, y]), label_smoothing=0.01).backward()
+        opt.step()
+    fitted = {"head.3.weight": W3.detach().clone(), "head.3.bias": b3.detach().clone()}
+    np.savez_compressed(os.path.join(GOLD, f"fitted_head_{name}.npz"), **{k: v.numpy() for k, v in fitted.items()})
+    sd.update(fitted)
+    ref.load_state_dict(sd)
+    with torch.no_grad():
+        lg = ref.head(f).numpy()
+        assert np.allclose(lg[:11], ref(ximg).numpy(), atol=1e-4)
+        lge = ref.head(fe).numpy()
+    out = {"image_logits": lg[:11], "fit_logits": lg[11:44], "heldout_logits": lg[44:],
+           "mx_emulation_logits": lge}
+    np.savez_compressed(os.path.join(GOLD, f"fitted_vectors_{name}.npz"), **out)
+    for k in ("image_logits", "fit_logits", "heldout_logits"):
+        srt = np.sort(out[k], axis=1)
+        print(name, k, "argmax", out[k].argmax(1).tolist(), "min margin %.2f" % (srt[:, -1] - srt[:, -2]).min())
+    print(name, "max |emulation - fp32| logits %.3f" % np.abs(lge - lg).max(), "emulation labels equal:",
+          bool((lge[:44].argmax(1) == lg[:44].argmax(1)).all()))
+    assert out["image_logits"].argmax(1).tolist() == list(range(11))
+    assert out["fit_logits"].argmax(1).tolist() == [j % 11 for j in range(33)]
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "fitted":
         for nm in FITTED:
             make_fitted(nm)
+    elif len(sys.argv) > 1 and sys.argv[1] == "fitted_big":
+        for nm in FITTED_BIG:
+            make_fitted_big(nm)
     else:
         main()

@@ -10,6 +10,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FITTED = {
     "R": (dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.0, backbone="resnet18"), 0),
     "P": (dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.0, backbone="patch16"), 5),
+    # BASELINE configs[3] / configs[4] at their own size (scripts/make_golden.py fitted_big: only head.3 is fitted)
+    "B": (dict(num_classes=11, embed_dim=768, num_heads=12, num_layers=12, dropout=0.0, backbone="patch16"), 8),
+    "L": (dict(num_classes=11, embed_dim=1024, num_heads=16, num_layers=24, dropout=0.0, backbone="patch16"), 9),
 }
 
 

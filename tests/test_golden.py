@@ -118,3 +118,30 @@ def test_oracle_reproduces_fitted_vectors_and_they_are_diverse(name):
     for k in ("image_logits", "fit_logits"):
         srt = np.sort(vec[k], axis=1)
         assert (srt[:, -1] - srt[:, -2]).min() > 3.0
+
+
+@pytest.mark.parametrize("name,n", [("B", 6), ("L", 3)])
+def test_oracle_reproduces_large_fitted_vectors(name, n):
+    """ViT-B/16- and ViT-L/16-scale fitted fixtures (BASELINE configs[3] / [4] at their own depth): the oracle reproduces
+    the committed logits on the first n spectrograms (a full pass of the 24-layer model over all 60 frames takes too
+    long for the CPU suite), the labels cover all 11 classes with margins > 3.5, and the CPU MX-fp8 emulation, whose
+    logits are recorded beside them, predicts the same labels."""
+    from oracle.ref_model import CNNViTHybridRef
+    from tests.fitted import FITTED, fitted_inputs, fitted_state_dict, fitted_vectors
+    cfg, _ = FITTED[name]
+    ref = CNNViTHybridRef(**cfg)
+    ref.load_state_dict(fitted_state_dict(name, {k: v.shape for k, v in ref.state_dict().items()}))
+    ref.eval()
+    vec = fitted_vectors(name)
+    ximg, _, _ = fitted_inputs()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        got = ref(ximg[:n]).numpy()
+    assert np.allclose(got, vec["image_logits"][:n], rtol=1e-3, atol=3e-3)
+    assert vec["image_logits"].argmax(1).tolist() == list(range(11))
+    assert vec["fit_logits"].argmax(1).tolist() == [j % 11 for j in range(33)]
+    for k in ("image_logits", "fit_logits"):
+        srt = np.sort(vec[k], axis=1)
+        assert (srt[:, -1] - srt[:, -2]).min() > 3.5
+    both = np.concatenate([vec["image_logits"], vec["fit_logits"]])
+    assert (vec["mx_emulation_logits"][:44].argmax(1) == both.argmax(1)).all()

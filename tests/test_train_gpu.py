@@ -61,6 +61,11 @@ CASES = [
 
 @pytest.mark.parametrize("name,cfg,B,grad_rel,grad_cos", CASES, ids=[c[0] for c in CASES])
 def test_one_training_step_matches_autograd(dev, name, cfg, B, grad_rel, grad_cos):
+    check_training_step(dev, name, cfg, B, grad_rel, grad_cos)
+
+
+def check_training_step(dev, name, cfg, B, grad_rel, grad_cos):
+    """Shared with tests/test_benched_path_gpu.py (the same comparison at the batch size bench.py times)."""
     from vit_amd.loss import cross_entropy
     from vit_amd.synth import micro_doppler_batch
     torch.set_num_threads(16)
