@@ -7,6 +7,11 @@
      patch16 (no BatchNorm): DP(2 x B) == one pass over the concatenated batch 2B, per tensor rel L2 <= 1e-3
      hybrid  (BatchNorm, per-replica statistics as DDP without SyncBN): DP(2 x B) == mean of the two replicas'
      stand-alone gradients, per tensor rel L2 <= 1e-3.
+1b. The REAL process group on one GPU: `init_process_group("nccl", world_size=1)` in a fresh child process, one hybrid
+   training step with `set_data_parallel()` and the reducer's test-only switch (exchange even in a world of one):
+   `all_reduce(async_op=True)` on flat-buffer slices, issued from the autograd thread behind queued kernels, goes
+   through ProcessGroupNCCL's stream / event logic and RCCL itself.  Gradients must be BIT-equal to the step without
+   DP (a sum over one rank, pre-scaled by 1/1), >= 4 buckets issued.
 2. Two real ranks sharing this one GPU (gloo; RCCL cannot put two ranks on one device): `bench.py --gpus 2` exactly as
    the driver runs it, but with WORLD_SIZE unset so bench.py starts its own launcher; the JSON line must say n_gpus 2
    and carry a training figure, exit status 0.  The numbers mean nothing (one card); the code path is what is tested.
@@ -100,7 +105,7 @@ def test_two_replicas_through_bucket_reducer(dev, name, cfg, B):
     eng = m.train_engine
     red = BucketReducer.__new__(BucketReducer)
     fake = _FakeDist(g_b)
-    red.dist, red.group, red.world = fake, None, 2
+    red.dist, red.group, red.world, red.active = fake, None, 2, True
     red.total, red.bucket_elems = eng.layout.total, (1 << 20) // 4
     red.mode, red.presync, red.done, red.buckets, red._works, red._stream = None, False, 0, [], [], None
     eng.reducer = red
@@ -148,3 +153,72 @@ def test_bench_two_ranks_on_one_card():
     assert "error" not in out["train"], out["train"]
     assert out["train"]["global_batch"] == 32 and out["train"]["value"] > 0
     assert "all-reduce" in out["train"]["includes"]
+
+
+_RCCL_CHILD = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["RVIT_ROOT"])
+import torch
+import torch.distributed as dist
+from vit_amd.loss import cross_entropy
+from vit_amd.model import CNNViTHybrid
+from vit_amd.synth import micro_doppler_batch, synth_state_dict
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+cfg = dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18")
+m = CNNViTHybrid(**cfg)
+m.load_state_dict(synth_state_dict({k: v.shape for k, v in m.state_dict().items()}, 4))
+m = m.to(dev).train()
+bn = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "tracked" in k}
+B = 16
+x = micro_doppler_batch(B, seed=31).to(dev)
+y = (torch.arange(B) % 11).to(dev)
+
+def step():
+    m.load_state_dict(bn, strict=False)
+    for p in m.parameters():
+        p.grad = None
+    torch.manual_seed(5)                      # the dropout sites draw their seeds from torch's CPU generator
+    loss = cross_entropy(m(x), y, label_smoothing=0.05)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.item(), m.train_engine.last_flat.clone()
+
+l0, g0 = step()
+l0b, g0b = step()
+m.set_data_parallel(bucket_mb=1.0)
+red = m.train_engine.reducer
+assert not red.active                         # a world of one exchanges nothing by default
+red.active = True
+res = []
+for _ in range(3):
+    l1, g1 = step()
+    res.append((l1, bool(torch.equal(g1, g0)), len(red.buckets), red.mode,
+                red.buckets[0][0] == 0 and red.buckets[-1][1] == red.total
+                and all(a[1] == b[0] for a, b in zip(red.buckets, red.buckets[1:]))))
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"loss0": l0, "repro": bool(torch.equal(g0, g0b)), "steps": res,
+                              "backend": "nccl", "finite": bool(torch.isfinite(g0).all())}))
+"""
+
+
+def test_real_rccl_process_group_on_one_gpu(dev, tmp_path):
+    env = dict(os.environ, RVIT_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RVIT_DP_MODE", "RVIT_DP_FORCE"):
+        env.pop(k, None)
+    script = tmp_path / "rccl_child.py"
+    script.write_text(_RCCL_CHILD)
+    r = subprocess.run([sys.executable, "-u", str(script)], env=env, capture_output=True, text=True, timeout=240)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, tail
+    res = json.loads(line[-1][7:])
+    print("\n[rccl world 1]", res)
+    assert res["finite"] and res["repro"]          # ordered reductions: the plain step is bit-reproducible
+    for loss, equal, nb, mode, tiles in res["steps"]:
+        assert mode == "async" and nb >= 4 and tiles
+        assert equal, "gradients after the RCCL exchange differ from the step without DP"
+        assert loss == res["loss0"]

@@ -146,6 +146,53 @@ def test_fused_step_same_gradients_tight(dev, backbone):
         assert torch.allclose(ma(x), mb(x), atol=1e-3)
 
 
+def test_unfreeze_restarts_the_stem_bias_correction_like_torch(dev):
+    """freeze_backbone for N steps, then unfreeze (train_vit.py:310-318, 918-923): torch.optim.AdamW creates a
+    parameter's state at its FIRST gradient, so the stem's bias correction starts at step 1 after the unfreeze while
+    the tail is at step N + 1 (one global counter made the first stem updates ~3x too large).  Same
+    gradients into both optimisers every step; parameters, moments and state['step'] must track torch.optim.AdamW."""
+    from vit_amd.loss import CrossEntropyLoss
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.optim import FusedAdamW
+    from vit_amd.synth import micro_doppler_batch, synth_state_dict
+    cfg = dict(num_classes=11, embed_dim=128, num_heads=2, num_layers=2, dropout=0.0, backbone="resnet18")
+    ma, mb = CNNViTHybrid(**cfg), CNNViTHybrid(**cfg)
+    sd = synth_state_dict({k: v.shape for k, v in ma.state_dict().items()}, 5)
+    ma.load_state_dict(sd); mb.load_state_dict(sd)
+    ma, mb = ma.to(dev).train(), mb.to(dev).train()
+    stock = torch.optim.AdamW(ma.parameters(), lr=5e-4, weight_decay=0.05)
+    fused = FusedAdamW(mb, lr=5e-4, weight_decay=0.05, max_grad_norm=1.0)
+    x = micro_doppler_batch(8, seed=6).to(dev)
+    y = torch.randint(0, 11, (8,), generator=torch.Generator().manual_seed(3)).to(dev)
+    crit = CrossEntropyLoss(label_smoothing=0.05)
+    N, K = 5, 4
+    for step in range(N + K):
+        frozen = step < N
+        for m in (ma, mb):
+            for p in m.cnn_backbone.parameters():
+                p.requires_grad = not frozen
+        stock.zero_grad(set_to_none=True)
+        fused.zero_grad(set_to_none=True)
+        crit(mb(x), y).backward()
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            pa.grad = None if pb.grad is None else pb.grad.detach().clone()
+        torch.nn.utils.clip_grad_norm_([p for p in ma.parameters() if p.grad is not None], 1.0)
+        stock.step()
+        fused.step()
+        for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-6), (step, n, (pa - pb).abs().max().item())
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        sa, sb = stock.state[pa], fused.state[pb]
+        want = K if n.startswith("cnn_backbone.") else N + K
+        assert int(sa["step"]) == want and int(sb["step"]) == want, (n, int(sa["step"]), int(sb["step"]))
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-4, atol=1e-8), n
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-4, atol=1e-12), n
+    # state_dict round trip keeps both counters
+    import copy as _copy
+    fused.load_state_dict(_copy.deepcopy(fused.state_dict()))
+    assert fused._step == N + K and fused._step_stem == K
+
+
 def _flatten(node, pref=""):
     if torch.is_tensor(node):
         yield pref, node

@@ -50,7 +50,7 @@ MODES = ("async", "side", "inline", "staged")
 
 class BucketReducer:
     def __init__(self, total: int, process_group=None, bucket_bytes: int = 8 << 20, mode: Optional[str] = None,
-                 presync: Optional[bool] = None):
+                 presync: Optional[bool] = None, exchange_at_world_one: Optional[bool] = None):
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
@@ -63,6 +63,11 @@ class BucketReducer:
         if self.mode is not None and self.mode not in MODES:
             raise ValueError(f"BucketReducer: mode {self.mode!r} not in {MODES}")
         self.presync = bool(int(os.environ.get("RVIT_DP_PRESYNC", "0"))) if presync is None else bool(presync)
+        # test-only switch (RVIT_DP_FORCE=1): a world of one normally exchanges nothing; with it every bucket is issued
+        # anyway, which puts the product issue path (async all_reduce of flat-buffer slices from the autograd thread,
+        # behind queued kernels) through the real process group on ONE GPU (tests/test_dp_gpu.py, backend "nccl")
+        force = bool(int(os.environ.get("RVIT_DP_FORCE", "0"))) if exchange_at_world_one is None else bool(exchange_at_world_one)
+        self.active = self.world > 1 or force
         self.done = 0
         self.buckets: List[Tuple[int, int]] = []  # (start, end) of every bucket launched in this step
         self._works: list = []
@@ -120,7 +125,7 @@ class BucketReducer:
 
     def ready(self, flat: torch.Tensor, upto: int) -> None:
         """Elements [0, upto) of `flat` are final; launch a bucket if enough has accumulated."""
-        if self.world <= 1:
+        if not self.active:
             return
         if upto - self.done >= self.bucket_elems:
             self._launch(flat, self.done, upto)
@@ -128,7 +133,7 @@ class BucketReducer:
     def finish(self, flat: torch.Tensor, limit: Optional[int] = None) -> None:
         """Exchange what is left of [0, limit) (default: the whole buffer; a frozen stem leaves its tail out: every
         rank must pass the same limit) and wait for every bucket of the step."""
-        if self.world <= 1:
+        if not self.active:
             return
         total = self.total if limit is None else min(int(limit), self.total)
         if self.done < total:

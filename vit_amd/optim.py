@@ -48,11 +48,20 @@ class FusedAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self._norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # torch.optim.AdamW keeps one step count PER PARAMETER, created at the parameter's first gradient: after
+        # unfreeze_backbone() (train_vit.py:918-923) the stem's bias correction starts at step 1 while the tail is at
+        # step N+1.  Two counters cover that (the only frozen set supported is the whole stem = the tail of the flat
+        # layout): `_step` for [0, stem_start), `_step_stem` for [stem_start, total), the latter advanced only on steps
+        # where the stem is active.  While they are equal the whole buffer is one launch.
         self._step = 0
+        self._step_stem = 0
         m_views, v_views = eng.grads_in_param_order(self.exp_avg), eng.grads_in_param_order(self.exp_avg_sq)
         self._step_t = torch.tensor(0.0)
+        self._step_stem_t = torch.tensor(0.0)
+        stem = set() if model.cnn_backbone is None else {id(p) for p in model.cnn_backbone.parameters()}
+        self._stem_ids = stem
         for p, mv, vv in zip(model.parameters(), m_views, v_views):
-            self.state[p] = {"step": self._step_t, "exp_avg": mv, "exp_avg_sq": vv}
+            self.state[p] = {"step": self._step_stem_t if id(p) in stem else self._step_t, "exp_avg": mv, "exp_avg_sq": vv}
         named = list(model.named_parameters())
         self._probe = [(p, eng.layout.offsets[n]) for n, p in (named[0], named[-1])]
         # bf16 operand copies for the training engine, written by the AdamW kernel from now on
@@ -91,21 +100,31 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise RuntimeError("FusedAdamW.step: parameter gradients are not views of the engine's flat buffer "
                                    "(gradient accumulation over several backward passes is not supported)")
         grp = self.param_groups[0]
+        total = self._eng.layout.total
+        stem_active = bool(self._stem_ids) and n_active == total
         self._step += 1
+        if stem_active:
+            self._step_stem += 1
+        if stem_active and self._step_stem != self._step:
+            ranges = [(slice(0, self._eng.stem_start()), self._step), (slice(self._eng.stem_start(), total), self._step_stem)]
+        else:
+            ranges = [(slice(0, n_active), self._step)]
         norm = None
         with torch.cuda.device(self.flat_params.device):
-            act = slice(0, n_active)
-            if self.max_grad_norm is not None:
+            if self.max_grad_norm is not None:       # ONE norm over everything that is stepped (clip_grad_norm_)
                 self._norm_sq.zero_()
-                norm = ops.sumsq(flat_g[act], self._norm_sq)
+                norm = ops.sumsq(flat_g[:n_active], self._norm_sq)
             b1, b2 = grp["betas"]
-            ops.adamw_step(self.flat_params[act], flat_g[act], self.exp_avg[act], self.exp_avg_sq[act], lr=grp["lr"],
-                           beta1=b1, beta2=b2, eps=grp["eps"], weight_decay=grp["weight_decay"], step=self._step,
-                           grad_norm_sq=norm, max_grad_norm=float(self.max_grad_norm or 0.0),
-                           params_bf16=self.mirror.bf16[act])
+            for rng, step in ranges:
+                ops.adamw_step(self.flat_params[rng], flat_g[rng], self.exp_avg[rng], self.exp_avg_sq[rng], lr=grp["lr"],
+                               beta1=b1, beta2=b2, eps=grp["eps"], weight_decay=grp["weight_decay"], step=step,
+                               grad_norm_sq=norm, max_grad_norm=float(self.max_grad_norm or 0.0),
+                               params_bf16=self.mirror.bf16[rng])
             self.mirror.refresh(full=False)      # K-major copies for the backward GEMMs: one batched-transpose launch
         self.model.invalidate_packs()        # inference engine: re-pack at the next eval forward
-        self._step_t += 1     # one tensor shared by every parameter's state entry
+        self._step_t += 1     # one tensor shared by the state entries of the tail's parameters, one by the stem's
+        if stem_active:
+            self._step_stem_t += 1
         return None
 
     def grad_norm(self) -> torch.Tensor:
@@ -120,7 +139,9 @@ class FusedAdamW(torch.optim.Optimizer):
             new = self.state[p]
             old["exp_avg"].copy_(new["exp_avg"])
             old["exp_avg_sq"].copy_(new["exp_avg_sq"])
-            self._step_t.fill_(float(new["step"]))
-            old["step"] = self._step_t
+            t = self._step_stem_t if id(p) in self._stem_ids else self._step_t
+            t.fill_(float(new["step"]))
+            old["step"] = t
             self.state[p] = old
         self._step = int(float(self._step_t))
+        self._step_stem = int(float(self._step_stem_t))
