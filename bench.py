@@ -42,6 +42,30 @@ HBM_PEAK_GBS = 8000.0            # spec, MI355X_MICROARCH.md:36
 FWD_FLOPS_PER_SAMPLE = 3.965e9   # BASELINE.md §2 (R hybrid)
 
 
+def host_info():
+    """CPU model and PHYSICAL core count of this box (SURVEY.md §8d asks for both beside the CPU baseline); `cores` in
+    a cpu_baseline object is the number of threads the oracle actually used."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "processor":
+                    logical += 1
+                elif k == "physical id":
+                    pid = v
+                elif k == "core id":
+                    cid = v
+                    phys.add((pid, cid))
+    except OSError:
+        pass
+    return {"cpu_model": model, "host_physical_cores": len(phys) or None, "host_logical_cpus": logical or os.cpu_count()}
+
+
 def cpu_baseline(sd, seconds=20.0, batch=8):
     """Oracle (kind='port': same torch.nn calls as the reference, train_vit.py:93-127 + ResNet-18
     restatement) on the host cores; mirrors the reference's batch-8 loop (infer.py:459-469)."""
@@ -63,7 +87,7 @@ def cpu_baseline(sd, seconds=20.0, batch=8):
         dt = time.perf_counter() - t0
     return {"value": round(n * batch / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n} forwards of batch {batch}, torch {torch.__version__} fp32 eval fast path, "
-                      f"same weights/inputs generator"}
+                      f"same weights/inputs generator", **host_info()}
 
 
 def cpu_train_baseline(sd, cfg, steps=4, batch=32, seconds=25.0):
@@ -95,7 +119,8 @@ def cpu_train_baseline(sd, cfg, steps=4, batch=32, seconds=25.0):
         n += 1
     dt = time.perf_counter() - t0
     return {"value": round(n * batch / dt, 2), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} optimiser steps of batch {batch} (fp32, torch {torch.__version__}), same model / loss / optimiser"}
+            "sample": f"{n} optimiser steps of batch {batch} (fp32, torch {torch.__version__}), same model / loss / optimiser",
+            **host_info()}
 
 
 def max_over_ranks(dist, dt: float, dev) -> float:
@@ -114,7 +139,31 @@ def _say(rank, msg):
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
 
-def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PER_SAMPLE):
+def kernel_roofline(kernels, peak, steps):
+    """Roofline object of the dominant MFMA kernel of a leg from its HIP-event records {name: {ms, flops, launches}}
+    (the spans of vit_amd/ops.py carry the algorithmic FLOPs of each launch), and the same figure per kernel family."""
+    mf = {n: k for n, k in kernels.items() if k["flops"] > 0}
+    if not mf:
+        return None, {}
+    dom = max(mf, key=lambda n: mf[n]["ms"])
+    k = mf[dom]
+    ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+    roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(ach / peak, 4), "traffic": None, "avg_launch_us": round(k["ms"] / k["launches"] * 1e3, 2),
+            "launches_per_step": k["launches"] // steps, "ms_per_step": round(k["ms"] / steps, 3)}
+    fam = {}
+    for n, k in mf.items():
+        f = "attn" if n.startswith("attn") else "wgrad" if "wgrad" in n else "gemm" if n.startswith("gemm") else n
+        d = fam.setdefault(f, {"ms": 0.0, "flops": 0.0})
+        d["ms"] += k["ms"]
+        d["flops"] += k["flops"]
+    split = {f: {"ms_per_step": round(d["ms"] / steps, 3), "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
+                 "frac_of_peak": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / peak, 4)} for f, d in sorted(fam.items())}
+    return roof, split
+
+
+def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PER_SAMPLE, batch=None, steps=None,
+              profile=True, cpu=True):
     """Secondary figure (BASELINE.json configs[3] shape on the R model): one optimiser step =
     forward in train() mode (BatchNorm batch statistics) + label-smoothed CE + backward on librvit +
     bucketed gradient all-reduce (N>1, overlapped with backward) + grad-norm clipping + AdamW
@@ -132,7 +181,8 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
     model = model.to(dev).train()
     if world > 1:
         model.set_data_parallel()
-    B = args.train_batch
+    B = args.train_batch if batch is None else batch
+    n_steps = args.train_steps if steps is None else steps
     x = torch.cat([micro_doppler_batch(min(64, B - i), seed=99 + 1000 * rank + i) for i in range(0, B, 64)]).to(dev)
     y = torch.randint(0, cfg["num_classes"], (B,), generator=torch.Generator().manual_seed(rank)).to(dev)
     fused = not args.stock_optimizer
@@ -164,7 +214,7 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
     sync()
     _say(rank, "train: timed steps")
     t0 = time.perf_counter()
-    for _ in range(args.train_steps):
+    for _ in range(n_steps):
         loss = step()
     t_host = time.perf_counter() - t0      # host time to ENQUEUE the steps (before the sync): launch-bound if ~ dt
     sync()
@@ -172,7 +222,7 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dist, dt, dev)
     kernels = {}
-    if rank == 0 or dist is not None:  # every rank must run the same collectives
+    if profile and (rank == 0 or dist is not None):  # every rank must run the same collectives
         rec = []
         ops.set_profiler(rec)
         for _ in range(2):
@@ -180,28 +230,34 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
         torch.cuda.synchronize(dev)
         ops.set_profiler(None)
         for name, e0, e1, fl, nb in rec:
-            kernels[name] = kernels.get(name, 0.0) + e0.elapsed_time(e1) / 2
+            k = kernels.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            k["launches"] += 1
+            k["ms"] += e0.elapsed_time(e1)
+            k["flops"] += fl
     if rank != 0:
         return None
-    sps = world * B * args.train_steps / dt
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline and cfg["embed_dim"] <= 256:   # the R model only: ViT-B steps take minutes on a CPU
-        cpu = cpu_train_baseline(sd, cfg)
-    return {"metric": "train_samples_per_sec", "cpu_baseline": cpu, "value": round(sps, 1), "unit": "samples/s",
-            "ms_per_step": round(dt / args.train_steps * 1e3, 3),
-            "host_enqueue_ms_per_step": round(t_host / args.train_steps * 1e3, 3), "steps": args.train_steps,
+    sps = world * B * n_steps / dt
+    cpu_res = None
+    if cpu and world == 1 and not args.no_cpu_baseline and cfg["embed_dim"] <= 256:   # the R model only: ViT-B steps take minutes on a CPU
+        cpu_res = cpu_train_baseline(sd, cfg)
+    roof, split = kernel_roofline(kernels, BF16_MFMA_PEAK_TFLOPS, 2)
+    return {"metric": "train_samples_per_sec", "cpu_baseline": cpu_res, "value": round(sps, 1), "unit": "samples/s",
+            "ms_per_step": round(dt / n_steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(t_host / n_steps * 1e3, 3), "steps": n_steps, "warmup": 3,
+            "dtype": "bf16", "roofline": roof, "kernel_families": split,
             "batch_per_gpu": B,
             "global_batch": world * B, "dropout": cfg["dropout"], "final_loss": round(float(loss.detach()), 4),
             "includes": "forward(train-mode BN) + CE(label_smoothing=0.05) + backward + "
                         + ("bucketed RCCL all-reduce + " if world > 1 else "") + ("librvit fused clip+AdamW" if fused else "clip_grad_norm_ + torch AdamW(fused=True)"),
             "model_tflops": round(sps * 3 * fwd_flops / 1e12, 2),
             "mfma_util_model": round(sps * 3 * fwd_flops / 1e12 / (BF16_MFMA_PEAK_TFLOPS * world), 4),
-            "kernel_ms_per_step": {n: round(v, 4) for n, v in sorted(kernels.items())}}
+            "kernel_ms_per_step": {n: round(v["ms"] / 2, 4) for n, v in sorted(kernels.items())}}
 
 
-def vitl_infer(args, dev, dist, world, rank):
+def vitl_infer(args, dev, dist, world, rank, batch=None, steps=None, warmup=None):
     """BASELINE.json configs[4]: ViT-L/16-scale forward, encoder Linears on the MX-fp8 MFMA; the same model in
-    bf16 is timed beside it.  Weights: random normal (std 0.02, torch generator) - throughput only."""
+    bf16 is timed beside it.  Weights: random normal (std 0.02, torch generator) - throughput only.  Returns the
+    result object on rank 0 (None elsewhere)."""
     from vit_amd import ops
     from vit_amd.model import CNNViTHybrid
     from vit_amd.synth import micro_doppler_batch
@@ -212,7 +268,9 @@ def vitl_infer(args, dev, dist, world, rank):
             if p.dim() >= 2:
                 p.normal_(0.0, 0.02)
     model = model.to(dev).eval()
-    B = args.batch if args.batch != 512 else 256   # configs[4] sweeps 8..1024; 256 unless --batch says otherwise
+    B = batch if batch is not None else (args.batch if args.batch != 512 else 256)   # configs[4] sweeps 8..1024; 256 by default
+    n_steps = args.steps if steps is None else steps
+    n_warm = args.warmup if warmup is None else warmup
     x = torch.cat([micro_doppler_batch(min(64, B - i), seed=1234 + 1000 * rank + i) for i in range(0, B, 64)]).to(dev)
 
     def sync():
@@ -226,11 +284,11 @@ def vitl_infer(args, dev, dist, world, rank):
     for prec in ("bf16", "mxfp8"):
         model.set_inference_precision(prec)
         with torch.no_grad():
-            for _ in range(args.warmup):
+            for _ in range(n_warm):
                 model(x)
             sync()
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(n_steps):
                 model(x)
             sync()
             dt = time.perf_counter() - t0
@@ -250,13 +308,12 @@ def vitl_infer(args, dev, dist, world, rank):
                 k["ms"] += e0.elapsed_time(e1)
                 k["flops"] += fl
     if rank != 0:
-        return
+        return None
     dt = res["mxfp8"]
-    value = world * B * args.steps / dt
-    g = kernels["gemm_mxfp8"]
-    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    value = world * B * n_steps / dt
+    roof, split = kernel_roofline(kernels, FP8_MFMA_PEAK_TFLOPS, 2)
     out = {"metric": "inference_frames_per_sec", "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "steps": n_steps, "warmup": n_warm, "ms_per_step": round(dt / n_steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-e4m3 (MX)",
            "data": "synthetic",
            "config": {"workload": "ViT-L/16-scale radar ViT (patch16, E1024/H16/L24, 11 classes) batched inference, "
@@ -264,13 +321,11 @@ def vitl_infer(args, dev, dist, world, rank):
                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}"},
            "model_tflops": round(value * VITL_FWD_FLOPS_PER_SAMPLE / 1e12, 2),
            "mfma_util_model": round(value * VITL_FWD_FLOPS_PER_SAMPLE / 1e12 / (FP8_MFMA_PEAK_TFLOPS * world), 4),
-           "roofline": {"kernel": "gemm_mxfp8", "bound": "mfma", "achieved": round(ach, 2), "peak": FP8_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / FP8_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                        "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2)},
-           "bf16_same_model": {"value": round(world * B * args.steps / res["bf16"], 1), "unit": "frames/s",
-                               "ms_per_step": round(res["bf16"] / args.steps * 1e3, 3)},
+           "roofline": roof, "kernel_families": split,
+           "bf16_same_model": {"value": round(world * B * n_steps / res["bf16"], 1), "unit": "frames/s",
+                               "ms_per_step": round(res["bf16"] / n_steps * 1e3, 3)},
            "kernel_ms_per_step": {n: round(v["ms"] / 2, 4) for n, v in sorted(kernels.items())}}
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def spawn_ranks(n: int) -> int:
@@ -309,6 +364,8 @@ def main():
     ap.add_argument("--stock-optimizer", action="store_true",
                     help="training legs: clip_grad_norm_ + torch.optim.AdamW(fused=True) instead of vit_amd.optim.FusedAdamW")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-throughput leg")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the ViT-B/16-scale training and ViT-L/16-scale MX-fp8 inference legs (BASELINE configs[3], [4])")
     ap.add_argument("--train-timeout", type=float, default=240.0,
                     help="seconds after which a stalled training leg is abandoned (the inference line is still printed)")
     ap.add_argument("--workload", choices=["hybrid", "vitb-train", "vitl-infer-fp8"], default="hybrid",
@@ -355,6 +412,7 @@ def main():
                                           + tr["includes"], "batch_per_gpu": tr["batch_per_gpu"],
                               "global_batch": tr["global_batch"], "parallelism": f"dp{world}"},
                    "model_tflops": tr["model_tflops"], "mfma_util_model": tr["mfma_util_model"],
+                   "roofline": tr["roofline"], "kernel_families": tr["kernel_families"],
                    "kernel_ms_per_step": tr["kernel_ms_per_step"]}
             print(json.dumps(out), flush=True)
         if dist is not None:
@@ -363,7 +421,9 @@ def main():
         return
 
     if args.workload == "vitl-infer-fp8":
-        vitl_infer(args, dev, dist, world, rank)
+        res = vitl_infer(args, dev, dist, world, rank)
+        if rank == 0:
+            print(json.dumps(res), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -466,19 +526,22 @@ def main():
             "kernel_ms_per_step": {n: round(v["ms"] / min(args.steps, 5), 4) for n, v in sorted(kernels.items())},
         }
 
-    train = None
+    # ---- secondary legs: BASELINE configs[2] (hybrid training), configs[3] (ViT-B/16-scale training), configs[4]
+    # (ViT-L/16-scale MX-fp8 inference).  The headline above is already measured: a leg that stalls (a wedged
+    # collective, a lost peer) must not lose it.  After --train-timeout seconds in ONE leg every rank gives up: rank 0
+    # still prints the line, with that leg's `error` set, and EVERY rank exits with status 3 - a process that touched
+    # the GPU and stalled has failed.
+    import gc
+    import threading
     if not args.no_train:
         del x
-        # The headline above is already measured: a secondary leg that stalls (a wedged collective, a lost peer)
-        # must not lose it.  After --train-timeout seconds every rank gives up: rank 0 still prints the line, with
-        # `train.error` set, and EVERY rank exits with status 3 - a process that touched the GPU and stalled has failed.
-        import threading
 
+    def run_leg(name, fn):
         def give_up():
             import faulthandler
             faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
             if out is not None:
-                out["train"] = {"error": f"training leg did not finish within {args.train_timeout:.0f} s; abandoned, exit status 3"}
+                out[name] = {"error": f"leg did not finish within {args.train_timeout:.0f} s; abandoned, exit status 3"}
                 print(json.dumps(out), flush=True)
             sys.stderr.flush()
             os._exit(3)
@@ -486,12 +549,41 @@ def main():
         dog = threading.Timer(args.train_timeout, give_up)
         dog.daemon = True
         dog.start()
-        train = train_leg(args, dev, dist, world, rank, sd)
+        _say(rank, f"leg {name}")
+        res = fn()
         dog.cancel()
+        gc.collect()
+        torch.cuda.empty_cache()
+        if out is not None and res is not None:
+            out[name] = res
+        return res
+
+    if not args.no_train:
+        train = run_leg("train", lambda: train_leg(args, dev, dist, world, rank, sd))
+        # SURVEY.md §8d config 3 names batch 32 (the reference's, train_vit.py:505-515) and 512 per GPU
+        sweep = []
+        for b in (32, 512):
+            if b != args.train_batch and not args.no_extra_legs:
+                r = run_leg(f"train_b{b}", lambda b=b: train_leg(args, dev, dist, world, rank, sd, batch=b, steps=8,
+                                                                  profile=False, cpu=False))
+                if out is not None:
+                    out.pop(f"train_b{b}", None)
+                    sweep.append({k: r[k] for k in ("batch_per_gpu", "global_batch", "value", "unit", "ms_per_step",
+                                                    "host_enqueue_ms_per_step", "steps", "mfma_util_model")})
+        if out is not None and train is not None:
+            train["other_batches"] = sweep
+    if not args.no_extra_legs:
+        def vitb():
+            tr = train_leg(args, dev, dist, world, rank, None, cfg=VITB_CFG, fwd_flops=VITB_FWD_FLOPS_PER_SAMPLE,
+                           batch=256, steps=6, cpu=False)
+            if tr is not None:
+                tr["config"] = {"workload": "ViT-B/16-scale radar ViT (patch16, E768/H12/L12, 11 classes) training step "
+                                            "(BASELINE configs[3])", "parallelism": f"dp{world}"}
+            return tr
+        run_leg("vitb_train", vitb)
+        run_leg("vitl_fp8", lambda: vitl_infer(args, dev, dist, world, rank, batch=256, steps=10, warmup=3))
 
     if rank == 0:
-        if train is not None:
-            out["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)

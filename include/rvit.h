@@ -40,11 +40,20 @@ extern "C" {
 
 /* Dropout (nn.Dropout(p) at train_vit.py:100,107,125 = pos_drop, the encoder layers' dropout /
  * dropout1 / dropout2 and the head's; attention-probability dropout, torch functional.py:6569-6570).
- * A site is keyed by (drop_p, drop_seed); element idx is kept iff the top 24 bits of
- * mix32(mix32(idx + lo32(seed)) ^ hi32(seed)) >= round(p * 2^24), kept values are scaled by 1/(1-p)
- * (mix32 = the "lowbias32" integer hash, csrc/common.h).  Nothing is stored: the backward entry
- * points regenerate the decision from the same (p, seed).  torch's Philox stream is NOT reproduced
- * (no kernel can): the distribution matches, the individual masks do not.
+ * A site is keyed by (drop_p, drop_seed).  The generator (csrc/common.h make_drop_key / rvit_drop_hash; restated in
+ * NumPy by oracle/ref_dropout.py keep_mask_numpy, and rvit_dropout_mask below must equal that bit for bit):
+ *   key      z = splitmix64 finaliser of drop_seed (z = seed + 0x9E3779B97F4A7C15; z = (z ^ z>>30) * 0xBF58476D1CE4E5B9;
+ *            z = (z ^ z>>27) * 0x94D049BB133111EB; z ^= z>>31), k0 = low 32 bits, k1 = high 32 bits;
+ *   pairs    ONE 32-bit hash decides the two neighbouring elements 2j and 2j+1 (pair index j = idx >> 1):
+ *            h = mix24(j + k0; 0xB5297B, 0x68E31D); h ^= h >> 15; h = mix24(h ^ k1; 0x9E3779, 0x7FEB35); h ^= h >> 16,
+ *            where mix24(x; a, b) = (x & 0xFFFFFF) * a + (x >> 8) * b mod 2^32 (each factor's low 24 bits);
+ *   decision element 2j is kept iff (h & 0xFFFF) >= T, element 2j+1 iff (h >> 16) >= T, T = round(p * 65536): the drop
+ *            probability is quantised to 1/65536; kept values are scaled by 1/(1-p) (of the unquantised p);
+ *   index    idx = row * cols + col of the tensor the site acts on (GEMM epilogues: the output matrix; rows of an even
+ *            width, so a pair never straddles rows; rvit_layernorm_bwd_drop uses (row * E + e) >> 1 likewise); the
+ *            attention-probability site uses ((image * H + head) * S + query) * S2 + key with S2 = S rounded up to even.
+ * Nothing is stored: the backward entry points regenerate the decision from the same (p, seed).  torch's Philox stream
+ * is NOT reproduced (no kernel can): the distribution matches, the individual masks do not.
  * drop_p == 0 disables.  Position of the dropout in a GEMM epilogue: */
 #define RVIT_DROP_PRE_RESIDUAL 1 /* C = act(drop(scale*acc + bias) + R): dropout1 / dropout2 */
 #define RVIT_DROP_POST_ACT 2     /* C = drop(act(... + R)): FFN / head dropout, pos_drop; also the mask multiply of

@@ -7,4 +7,4 @@ set -e
 cd "$(dirname "$0")/.."
 unset WORLD_SIZE RANK LOCAL_RANK
 RVIT_BENCH_VERBOSE=1 RVIT_DP_VERBOSE=1 GLOO_SOCKET_IFNAME=lo RVIT_BENCH_BACKEND=gloo timeout -k 10 200 python bench.py --gpus 2 \
-  --steps 3 --warmup 1 --batch 64 --train-batch 32 --train-steps 4 --train-timeout 120 --no-cpu-baseline
+  --steps 3 --warmup 1 --batch 64 --train-batch 32 --train-steps 4 --train-timeout 120 --no-cpu-baseline --no-extra-legs

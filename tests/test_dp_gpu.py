@@ -143,7 +143,7 @@ def test_bench_two_ranks_on_one_card():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
-           "--train-batch", "16", "--train-steps", "3", "--train-timeout", "90", "--no-cpu-baseline"]
+           "--train-batch", "16", "--train-steps", "3", "--train-timeout", "90", "--no-cpu-baseline", "--no-extra-legs"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert res.returncode == 0, res.stderr[-3000:]
