@@ -480,6 +480,8 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
   if (variant == 6) { RVIT_CHECK_ARG(patch_bytes + 3 * 64 * 128 <= 160 * 1024, "conv3x3: ring 3 does not fit"); return c3_launch<64, false, 8, 3>(a, patch_bytes, tile_len, st); }
   if (variant == 7) { RVIT_CHECK_ARG(patch_bytes + 4 * 64 * 128 <= 160 * 1024, "conv3x3: ring 4 does not fit"); return c3_launch<64, false, 8, 4>(a, patch_bytes, tile_len, st); }
   if (variant == 8) { RVIT_CHECK_ARG((a.N & 255) == 0 && patch_bytes + 3 * 256 * 128 <= 160 * 1024, "conv3x3: c256 ring 3 does not fit"); return c3_launch<256, false, 16, 3>(a, patch_bytes, tile_len, st); }
+  // round 3: the eight-wave four-phase kernel (conv3x3_p8.hip), tile 19 forces it
+  if (variant == 9) return rvit_conv3x3_p8(a, st);
   // 256 output channels per workgroup, sixteen waves of 64 x 64, one workgroup per CU: the patch is staged once per
   // 256 instead of 64 output channels and the fragment reads per MFMA drop from 0.75 to 0.5.  Same K order (bit-identical).
   // B=512: layer4 (512 -> 512, 7x7) 151 -> 135 us, layer3 (256 -> 256) 148 -> 144 us; automatic for >= 512 input

@@ -46,6 +46,8 @@ bool rvit_gemm8p_ok(const GemmArgs& a);                       // gemm8p.hip (256
 int rvit_gemm8p(const GemmArgs& a, hipStream_t stream);
 bool rvit_conv3x3_direct_ok(const GemmArgs& a);               // conv3x3.hip
 int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t stream);
+bool rvit_conv3x3_p8_ok(const GemmArgs& a);                   // conv3x3_p8.hip (eight waves, four-phase taps, one workgroup per CU)
+int rvit_conv3x3_p8(const GemmArgs& a, hipStream_t stream);
 bool rvit_conv3x3_c64_ok(const GemmArgs& a);                  // conv3x3_c64.hip (64 -> 64 channels, weights resident)
 int rvit_conv3x3_c64(const GemmArgs& a, hipStream_t stream);
 int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
