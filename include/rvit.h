@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 19
+#define RVIT_ABI_VERSION 20
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -121,6 +121,14 @@ int rvit_quantize_mxfp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_
 int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cpix, int seg_len, int KH,
                          int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* scale,
                          const float* bias, const void* residual, int act, int tile, void* stream);
+
+/* Which kernel rvit_conv2d_fwd_bf16 / rvit_conv2d_dgrad_bf16 run (tile 0) for a 3x3 / stride 1 / pad 1 convolution of B
+ * images of H x W x Cin -> Cout (16-byte aligned operands): 0 implicit-GEMM gather kernel, 1 generic direct kernel
+ * (conv3x3.hip), 2 weights-resident 64 -> 64 kernel (conv3x3_c64.hip), 3 its 256-channel sixteen-wave variant, 4 the
+ * eight-wave staggered kernel (conv3x3_p8.hip, chosen where its tiles fill whole rounds of the CUs).  Every choice gives the
+ * same bits; the query exists so that profilers can label launches (torch has no counterpart: cudnn picks silently,
+ * train_vit.py:711-714 `cudnn.benchmark`). */
+int rvit_conv3x3_kernel(int B, int H, int W, int Cin, int Cout);
 
 /* Input gradient of the convolution above (autograd of the stem convs): dx = conv_transpose(dy, w)
  * (+ residual, the gradient arriving over the other branch of a BasicBlock).

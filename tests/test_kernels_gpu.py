@@ -379,7 +379,7 @@ def test_errors_are_loud(dev):
 @pytest.mark.parametrize("cin,cout,hw,B", [(64, 64, 56, 2), (128, 128, 28, 3), (256, 256, 14, 5), (512, 512, 7, 11),
                                             (64, 128, 14, 1), (128, 64, 7, 40), (128, 256, 28, 2), (384, 128, 14, 3)])
 @pytest.mark.parametrize("plain", [False, True])
-@pytest.mark.parametrize("variant", [11, 12, 13, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [11, 12, 13, 15, 16, 17, 18, 19])
 def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant):
     """The LDS-resident 3x3/1 kernel (tile 10, csrc/conv3x3.hip) against torch and against the gather
     kernel (tile 1): tiles that straddle image rows and image boundaries (M = B*hw*hw is not a
@@ -392,6 +392,8 @@ def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant)
         pytest.skip("the 256-channel sixteen-wave variants need Cout and Cin multiples of 256")
     if variant in (16, 17) and hw == 56:
         pytest.skip("a 56-wide patch and a 3- / 4-stage weight ring do not fit the LDS")
+    if variant == 19 and (cout % 128 or cin % 128):
+        pytest.skip("the eight-wave staggered kernel needs Cout and Cin (dgrad: the roles swap) multiples of 128")
     g = torch.Generator().manual_seed(cin + cout + hw + B)
     x = _bf(torch.randn(B, hw, hw, cin, generator=g))
     w = _bf(torch.randn(cout, 3, 3, cin, generator=g) / math.sqrt(9 * cin))
@@ -424,6 +426,42 @@ def test_conv3x3_direct_forward_and_dgrad(dev, cin, cout, hw, B, plain, variant)
                      residual=None if plain else resx.to(dev))
     want = xr.grad.permute(0, 2, 3, 1) + (0 if plain else resx.float())
     _close(dx, want, 1.0 / 128, 2e-2, "direct dgrad")
+
+
+@pytest.mark.parametrize("c,hw,B", [(128, 28, 512), (256, 14, 512), (512, 7, 512), (256, 14, 77), (128, 28, 130),
+                                     (512, 7, 1000), (256, 28, 9), (128, 14, 3)])
+def test_conv3x3_eight_wave_kernel_bit_identical_at_full_size(dev, c, hw, B):
+    """csrc/conv3x3_p8.hip (tile 19; what layers 2-4 of the stem run at the benchmark's batch) against the generic direct
+    kernel (tile 11): BIT-EXACT (same 64-channel slice -> tap -> 32-deep MFMA step order), forward with the fused
+    BatchNorm / residual / ReLU epilogue and flipped (input-gradient) form, at the bench geometry (B=512: one image,
+    half an image, four images per tile: whole rounds of 256 workgroups) and at batch sizes whose tiles are ragged,
+    straddle images and leave wave rows partly or wholly empty.  Launched several times: a race between the weight
+    ring / patch DMA and the fragment reads of the two wave groups would show as rare differing tiles.  The automatic
+    choice (tile 0) must give the same bits whichever kernel it picks."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(c + hw + B)
+    x = _bf(torch.randn(B, hw, hw, c, generator=g)).to(dev)
+    w = _bf(torch.randn(c, 9 * c, generator=g) / math.sqrt(9 * c)).to(dev)
+    res = _bf(torch.randn(B, hw, hw, c, generator=g)).to(dev)
+    scale, bias = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+    want = torch.empty_like(x)
+    ops.conv2d(x, w, want, kh=3, kw=3, stride=1, pad=1, tile=11, scale=scale, bias=bias, residual=res, act="relu")
+    for rep in range(4):
+        got = torch.full_like(x, float("nan"))
+        ops.conv2d(x, w, got, kh=3, kw=3, stride=1, pad=1, tile=19 if rep < 3 else 0, scale=scale, bias=bias,
+                   residual=res, act="relu")
+        assert torch.equal(got, want), (rep, (got.float() - want.float()).abs().max().item())
+    want_plain, got_plain = torch.empty_like(x), torch.full_like(x, float("nan"))
+    ops.conv2d(x, w, want_plain, kh=3, kw=3, stride=1, pad=1, tile=11)
+    ops.conv2d(x, w, got_plain, kh=3, kw=3, stride=1, pad=1, tile=19)
+    assert torch.equal(got_plain, want_plain)
+    dx_want, dx_got = torch.empty_like(x), torch.full_like(x, float("nan"))
+    ops.conv2d_dgrad(x, w, dx_want, kh=3, kw=3, stride=1, pad=1, tile=11, residual=res)
+    ops.conv2d_dgrad(x, w, dx_got, kh=3, kw=3, stride=1, pad=1, tile=19, residual=res)
+    assert torch.equal(dx_got, dx_want)
+    assert ops._conv3x3_name(B, hw, hw, c, c) in ("conv3x3_p8", "conv3x3_direct", "conv3x3_c256")
+    if B == 512:
+        assert ops._conv3x3_name(B, hw, hw, c, c) == "conv3x3_p8"
 
 
 @pytest.mark.parametrize("B,H", [(1, 56), (3, 56), (2, 8), (37, 56), (300, 4)])

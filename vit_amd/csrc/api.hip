@@ -113,6 +113,14 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_conv3x3_kernel(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (long)B * H * W >= 0x7fffffffL) return RVIT_CONV_GATHER;
+  GemmArgs a{};
+  conv_geometry(a, nullptr, nullptr, B, H, W, Cin, Cin, 3, 3, 1, 1, H, W, Cout);
+  a.ldc = Cout; a.ldr = Cout; a.vec = (Cout & 7) == 0;
+  return rvit_conv3x3_auto(a);
+}
+
 int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int KH, int KW,
                            int stride, int pad, int Hx, int Wx, int Cin, const void* residual, int tile,
                            void* stream) {

@@ -449,6 +449,18 @@ static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream
   return RVIT_OK;
 }
 
+// Which kernel variant 0 (automatic) runs for this geometry: RVIT_CONV_* of rvit_internal.h.  One function, used by the
+// dispatcher below and by the query entry point rvit_conv3x3_kernel (profilers label launches with it).
+int rvit_conv3x3_auto(const GemmArgs& a) {
+  if (!rvit_conv3x3_direct_ok(a)) return RVIT_CONV_GATHER;
+  if (rvit_conv3x3_c64_ok(a)) return RVIT_CONV_C64;
+  if (rvit_conv3x3_p8_pays(a)) return RVIT_CONV_P8;
+  const int P = c3_patch_pixels(a.H, a.W);
+  const int patch_bytes = ((P + 7) / 8) * 1024;
+  if ((a.N & 255) == 0 && patch_bytes + 2 * 256 * 128 <= 160 * 1024 && a.Cpix >= 512) return RVIT_CONV_C256;
+  return RVIT_CONV_DIRECT;
+}
+
 // variant: 0 = automatic, 1 = BN 64 (single patch buffer), 2 = BN 128 with two patch buffers, 3 = BN 64 with
 // 4 waves of 64 x 64, 5 = BN 256 with sixteen waves of 64 x 64, 4 = the weights-resident 64 -> 64 channel kernel (conv3x3_c64.hip; automatic where it applies:
 // a property of the layer geometry, never of the batch size)
@@ -458,6 +470,7 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
     return rvit_conv3x3_c64(a, st);
   }
   if (variant == 0 && rvit_conv3x3_c64_ok(a)) return rvit_conv3x3_c64(a, st);
+  if (variant == 0 && rvit_conv3x3_p8_pays(a)) return rvit_conv3x3_p8(a, st);   // round 3: eight waves, staggered taps
   const int P = c3_patch_pixels(a.H, a.W);
   const int patch_bytes = ((P + 7) / 8) * 1024;
   const int tr = c3_tile_rows(a.H, a.W);

@@ -292,26 +292,21 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
   }
   const bool has_r = p.R != nullptr;
   const int relu = p.act == RVIT_ACT_RELU;
-  uint4 rn[2];
+  // every residual row of the wave is requested up front (the fragment registers are dead: 14 x 16 bytes per lane fit):
+  // one exposed memory latency per tile instead of one per fragment row
+  uint4 rr[C8_MF][2];
   if (has_r) {
-    int mr = mw0 + fr;
-    if (mr > m_last) mr = m_last;
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) rn[pr] = *reinterpret_cast<const uint4*>((const bf16*)p.R + (long)mr * p.ldr + nl[pr]);
+    for (int i0 = 0; i0 < C8_MF; ++i0) {
+      int mr = mw0 + i0 * 16 + fr;
+      if (mr > m_last) mr = m_last;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) rr[i0][pr] = *reinterpret_cast<const uint4*>((const bf16*)p.R + (long)mr * p.ldr + nl[pr]);
+    }
   }
 #pragma unroll
   for (int i0 = 0; i0 < C8_MF; ++i0) {
     const int m = mw0 + i0 * 16 + fr;
-    uint4 rc[2];
-    if (has_r) {
-      int mr = mw0 + (i0 < C8_MF - 1 ? i0 + 1 : i0) * 16 + fr;   // the next fragment row's residual before this row's stores
-      if (mr > m_last) mr = m_last;
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        rc[pr] = rn[pr];
-        if (i0 < C8_MF - 1) rn[pr] = *reinterpret_cast<const uint4*>((const bf16*)p.R + (long)mr * p.ldr + nl[pr]);
-      }
-    }
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       float v[8];
@@ -325,7 +320,7 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[pr][e] + bi[pr][e];
       if (has_r) {
-        const uint4 r = rc[pr];
+        const uint4 r = rr[i0][pr];
         v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
         v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
       }
@@ -347,6 +342,7 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
 struct C8Plan {
   int tn, tile_len, ppw, patch_bytes, lds;
   long tiles;
+  float eff;   // useful share of the MFMA work the launch issues: live pixel rows x filled rounds
 };
 
 // patch rows (padded-row space) the tile of pixels [m0, m0 + len) needs: R_last - R_first + 3, as the kernel computes
@@ -410,6 +406,8 @@ static bool c8_plan_compute(const GemmArgs& a, int num_cu, C8Plan* out) {
     if (pieces > 64 || lds > 160 * 1024) continue;
     out->tn = tn; out->tile_len = (int)len; out->ppw = (int)((len + wrows - 1) / wrows);
     out->patch_bytes = pieces * 1024; out->lds = lds; out->tiles = mt * ntn;
+    const long rounds = (out->tiles + num_cu - 1) / num_cu;
+    out->eff = (float)((double)a.M / ((double)mt * wrows * 16 * C8_MF) * ((double)out->tiles / ((double)rounds * num_cu)));
     return true;
   }
   return false;
@@ -434,6 +432,15 @@ bool rvit_conv3x3_p8_ok(const GemmArgs& a) {
   if ((a.N & 127) != 0 || a.Cpix < 128 || a.M >= (1L << 30)) return false;
   C8Plan pl;
   return c8_plan(a, c8_num_cu(), &pl);
+}
+
+// Does it pay?  Every workgroup multiplies 7 fragments per wave whatever its tile holds and owns its CU: the kernel wins
+// (B=512: layers 2 / 3 / 4 123 / 105 / 100 us against 133 / 118 / 106) when the tiles are nearly full and the rounds
+// nearly whole, and loses on small or odd batches.  Safe to decide by batch size: the results are bit-identical.
+bool rvit_conv3x3_p8_pays(const GemmArgs& a) {
+  C8Plan pl;
+  if (!rvit_conv3x3_direct_ok(a) || (a.N & 127) != 0 || a.Cpix < 128 || a.M >= (1L << 30)) return false;
+  return c8_plan(a, c8_num_cu(), &pl) && pl.eff >= 0.82f;
 }
 
 int rvit_conv3x3_p8(const GemmArgs& a, hipStream_t st) {

@@ -46,7 +46,10 @@ bool rvit_gemm8p_ok(const GemmArgs& a);                       // gemm8p.hip (256
 int rvit_gemm8p(const GemmArgs& a, hipStream_t stream);
 bool rvit_conv3x3_direct_ok(const GemmArgs& a);               // conv3x3.hip
 int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t stream);
+enum { RVIT_CONV_GATHER = 0, RVIT_CONV_DIRECT = 1, RVIT_CONV_C64 = 2, RVIT_CONV_C256 = 3, RVIT_CONV_P8 = 4 };
+int rvit_conv3x3_auto(const GemmArgs& a);                     // conv3x3.hip: the kernel tile 0 runs (RVIT_CONV_*)
 bool rvit_conv3x3_p8_ok(const GemmArgs& a);                   // conv3x3_p8.hip (eight waves, four-phase taps, one workgroup per CU)
+bool rvit_conv3x3_p8_pays(const GemmArgs& a);                 // ... and its tiles / rounds are full enough to win
 int rvit_conv3x3_p8(const GemmArgs& a, hipStream_t stream);
 bool rvit_conv3x3_c64_ok(const GemmArgs& a);                  // conv3x3_c64.hip (64 -> 64 channels, weights resident)
 int rvit_conv3x3_c64(const GemmArgs& a, hipStream_t stream);

@@ -6,6 +6,8 @@ module has a non-HIP implementation.
 """
 from __future__ import annotations
 
+import functools
+
 from typing import Optional, Tuple
 
 import torch
@@ -257,6 +259,12 @@ def gemm_mx(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.
     return out if out is not None else out_q
 
 
+@functools.lru_cache(maxsize=256)
+def _conv3x3_name(B: int, H: int, W: int, Cin: int, Cout: int) -> str:
+    code = _lib.load().rvit_conv3x3_kernel(B, H, W, Cin, Cout)
+    return ("conv2d_gather", "conv3x3_direct", "conv3x3_c64", "conv3x3_c256", "conv3x3_p8")[code]
+
+
 def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
            seg_len: Optional[int] = None, scale: Optional[torch.Tensor] = None,
            bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -279,18 +287,15 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
     lib = _lib.load()
     # algorithmic work: true taps only (the 7x7 stem conv's zero taps / 4th channel are padding)
     true_k = kh * kw * seg if seg_len is None else kh * (kw * seg - seg // 8 - (seg - seg // 8) // 4)
-    # the 3x3 / stride 1 / pad 1 convs run the LDS-resident-patch kernel (csrc/conv3x3.hip), everything else
-    # the implicit-GEMM gather kernel (csrc/gemm.hip): profile them under separate names
-    direct = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and seg_len is None and Cpix % 64 == 0
-              and Cout % 64 == 0 and (tile == 0 or 10 <= tile <= 19))
-    # ... and among those the 64 -> 64 channel convs on 56-wide maps (layer1) the weights-resident kernel
-    # (csrc/conv3x3_c64.hip; same conditions as rvit_conv3x3_c64_ok)
-    c64 = (direct and tile in (0, 14) and Cpix == 64 and Cout == 64 and W == 56 and H % 4 == 0
-           and not (residual is not None and act != "relu" and (scale is not None or bias is not None)))
-    # ... and the 256-channel sixteen-wave variant for >= 512 input channels (layer4; csrc/conv3x3.hip, same rule as
-    # rvit_conv3x3_direct; its LDS-fit condition always holds: patches are capped at 80 KB)
-    c256 = direct and not c64 and Cout % 256 == 0 and (tile == 15 or (tile == 0 and Cpix >= 512))
-    with _Span("conv3x3_c64" if c64 else "conv3x3_c256" if c256 else "conv3x3_direct" if direct else "conv2d_gather", 2 * B * Ho * Wo * Cout * true_k,
+    # profile the conv kernels under separate names: the library says which one tile 0 runs for a 3x3 / stride 1 /
+    # pad 1 geometry (rvit_conv3x3_kernel); a forced tile names its kernel itself
+    name = "conv2d_gather"
+    if kh == 3 and kw == 3 and stride == 1 and pad == 1 and seg_len is None:
+        if tile == 0:
+            name = _conv3x3_name(B, H, W, Cpix, Cout)
+        elif 10 <= tile <= 19:
+            name = {14: "conv3x3_c64", 15: "conv3x3_c256", 18: "conv3x3_c256", 19: "conv3x3_p8"}.get(tile, "conv3x3_direct")
+    with _Span(name, 2 * B * Ho * Wo * Cout * true_k,
                _nbytes(x, w, out, residual)):
         check(lib.rvit_conv2d_fwd_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cpix, seg, kh, kw, stride,
                                        pad, Ho, Wo, Cout, _ptr(scale), _ptr(bias), _ptr(residual), _ACT[act], tile,
