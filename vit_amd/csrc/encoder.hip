@@ -272,26 +272,42 @@ __global__ __launch_bounds__(EN_THREADS) void enc_mlp_kernel(float* __restrict__
 #undef ENC_W_LOAD
 
   // ---- bias, residual, store: all residual loads first (clamped rows), then the stores ---------------------------
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = wave * 32 + nt * 16 + fq * 4;
-    const float4 bb = *reinterpret_cast<const float4*>(b2 + col);
-    float4 xr[MT];
+  // v_permlane16_swap between lane rows of the wave's two 16-column blocks (fq 0<->1, 2<->3, as gemm8p.hip's epilogue)
+  // leaves every lane 8 consecutive columns of token row fr: the four lanes of a row read and write its WHOLE 128-byte
+  // line (round 2 wrote two 64-byte halves per line from two instructions: 43 % more write requests than bytes
+  // needed, profiles/r02_pmc_traffic.json).  Same sums in the same order: the bits do not change.
+  {
+    const int col = wave * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+    const float4 b0 = *reinterpret_cast<const float4*>(b2 + col), b1v = *reinterpret_cast<const float4*>(b2 + col + 4);
+    float4 xr[MT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int r = i * 16 + fr;
-      xr[i] = *reinterpret_cast<const float4*>(x + (row0 + (r < nrows ? r : 0)) * EN_E + col);
+      const float* xp = x + (row0 + (r < nrows ? r : 0)) * EN_E + col;
+      xr[i][0] = *reinterpret_cast<const float4*>(xp);
+      xr[i][1] = *reinterpret_cast<const float4*>(xp + 4);
     }
     ENC_PIN();
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int r = i * 16 + fr;
-      float4 o;
-      o.x = (accY[i][nt][0] + bb.x) + xr[i].x;
-      o.y = (accY[i][nt][1] + bb.y) + xr[i].y;
-      o.z = (accY[i][nt][2] + bb.z) + xr[i].z;
-      o.w = (accY[i][nt][3] + bb.w) + xr[i].w;
-      if (r < nrows) *reinterpret_cast<float4*>(x + (row0 + r) * EN_E + col) = o;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(accY[i][0][e]), __float_as_uint(accY[i][1][e]), false, false);
+        v[e] = __uint_as_float(sw2[0]);
+        v[4 + e] = __uint_as_float(sw2[1]);
+      }
+      float4 o0, o1;
+      o0.x = (v[0] + b0.x) + xr[i][0].x; o0.y = (v[1] + b0.y) + xr[i][0].y;
+      o0.z = (v[2] + b0.z) + xr[i][0].z; o0.w = (v[3] + b0.w) + xr[i][0].w;
+      o1.x = (v[4] + b1v.x) + xr[i][1].x; o1.y = (v[5] + b1v.y) + xr[i][1].y;
+      o1.z = (v[6] + b1v.z) + xr[i][1].z; o1.w = (v[7] + b1v.w) + xr[i][1].w;
+      if (r < nrows) {
+        float* xp = x + (row0 + r) * EN_E + col;
+        *reinterpret_cast<float4*>(xp) = o0;
+        *reinterpret_cast<float4*>(xp + 4) = o1;
+      }
     }
   }
 }
@@ -587,29 +603,42 @@ __global__ __launch_bounds__(EN_THREADS) void enc_attn_kernel(float* __restrict_
   }
 #undef ENC_QKV_LOAD
 
-  // ---- bias, residual, store ------------------------------------------------------------------------------
+  // ---- bias, residual, store (whole 128-byte lines per token row: lane swap as in enc_mlp_kernel) ---------------
   const bool img_ok = wm < n_img;
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int col = wn * 64 + nt * 16 + fq * 4;
-    const float4 bb = *reinterpret_cast<const float4*>(bout + col);
-    float4 xr[4];
+  for (int np = 0; np < 2; ++np) {
+    const int col = wn * 64 + np * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+    const float4 b0 = *reinterpret_cast<const float4*>(bout + col), b1v = *reinterpret_cast<const float4*>(bout + col + 4);
+    float4 xr[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int tk = i * 16 + fr;
       const bool ok = img_ok && tk < S;
-      xr[i] = *reinterpret_cast<const float4*>(x + (row0 + (ok ? wm * S + tk : 0)) * EN_E + col);
+      const float* xp = x + (row0 + (ok ? wm * S + tk : 0)) * EN_E + col;
+      xr[i][0] = *reinterpret_cast<const float4*>(xp);
+      xr[i][1] = *reinterpret_cast<const float4*>(xp + 4);
     }
     ENC_PIN();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int tk = i * 16 + fr;
-      float4 o;
-      o.x = (accY[i][nt][0] + bb.x) + xr[i].x;
-      o.y = (accY[i][nt][1] + bb.y) + xr[i].y;
-      o.z = (accY[i][nt][2] + bb.z) + xr[i].z;
-      o.w = (accY[i][nt][3] + bb.w) + xr[i].w;
-      if (img_ok && tk < S) *reinterpret_cast<float4*>(x + (row0 + wm * S + tk) * EN_E + col) = o;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(accY[i][2 * np][e]), __float_as_uint(accY[i][2 * np + 1][e]), false, false);
+        v[e] = __uint_as_float(sw2[0]);
+        v[4 + e] = __uint_as_float(sw2[1]);
+      }
+      float4 o0, o1;
+      o0.x = (v[0] + b0.x) + xr[i][0].x; o0.y = (v[1] + b0.y) + xr[i][0].y;
+      o0.z = (v[2] + b0.z) + xr[i][0].z; o0.w = (v[3] + b0.w) + xr[i][0].w;
+      o1.x = (v[4] + b1v.x) + xr[i][1].x; o1.y = (v[5] + b1v.y) + xr[i][1].y;
+      o1.z = (v[6] + b1v.z) + xr[i][1].z; o1.w = (v[7] + b1v.w) + xr[i][1].w;
+      if (img_ok && tk < S) {
+        float* xp = x + (row0 + wm * S + tk) * EN_E + col;
+        *reinterpret_cast<float4*>(xp) = o0;
+        *reinterpret_cast<float4*>(xp + 4) = o1;
+      }
     }
   }
 }
