@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 20
+#define RVIT_ABI_VERSION 21
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -332,6 +332,19 @@ int rvit_encoder_mlp_fwd(float* x, const float* gamma, const float* beta, float 
 int rvit_encoder_attn_fwd(float* x, const float* gamma, const float* beta, float eps, const void* wqkv,
                           const float* bqkv, const void* wout, const float* bout, int B, int S, int E, int H,
                           void* stream);
+
+/* The whole pre-LN encoder stack for inference in ONE launch, in place on the fp32 residual stream: for every layer
+ *   x += out_proj(softmax(q k^T / 8) v), q | k | v = in_proj(LayerNorm(x));   x += linear2(gelu(linear1(LayerNorm(x))))
+ * (`self.transformer(x)`, train_vit.py:112-116,163; torch transformer.py:539-553 the loop, :945-950 the layer).  A
+ * workgroup owns two whole images from the first LayerNorm to the last residual add (attention mixes the tokens of one
+ * image only), so no workgroup waits for another and the layers need no kernel boundary between them.  The arithmetic is
+ * that of rvit_encoder_attn_fwd / rvit_encoder_mlp_fwd: same bits as calling those per layer.
+ *   x: f32 [B*S, E], E == 256, H == 4, 2 S <= 112, hidden % 256 == 0, n_layers <= 16, one eps for every LayerNorm;
+ *   layer_params: HOST array of 12 device pointers per layer: norm1.weight, norm1.bias (f32 [E]), in_proj_weight (bf16
+ *   [3E, E]), in_proj_bias (f32 [3E]), out_proj.weight (bf16 [E, E]), out_proj.bias (f32 [E]), norm2.weight, norm2.bias,
+ *   linear1.weight (bf16 [hidden, E]), linear1.bias (f32 [hidden]), linear2.weight (bf16 [E, hidden]), linear2.bias. */
+int rvit_encoder_stack_fwd(float* x, const void* const* layer_params, int n_layers, float eps, int B, int S, int E, int H,
+                           int hidden, void* stream);
 
 /* LayerNorm backward fused with the residual-gradient accumulation of the pre-LN block
  * (x + f(LN(x)), torch transformer.py:947-950):  dx (+)= LN'(dy); dgamma += ..., dbeta += ...

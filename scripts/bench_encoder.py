@@ -62,3 +62,23 @@ print(f"attn per-op T={T}: {timeit(attn_per_op):8.1f} us", flush=True)
 y.copy_(x)
 us = timeit(lambda: ops.encoder_attn(y, WA["ln_w"], WA["ln_b"], WA["wqkv"], WA["bqkv"], WA["wout"], WA["bout"], B, S, 4, 1e-5))
 print(f"attn fused  T={T}: {us:8.1f} us", flush=True)
+
+# the whole stack (4 layers) in one launch against eight launches
+from test_encoder_gpu import _attn_weights as _aw, _mlp_weights as _mw  # noqa: E402
+lays, refs = [], []
+for li in range(4):
+    A, M = _aw(E, dev, 10 * li + 1), _mw(E, hidden, dev, 10 * li + 2)
+    lays.append((A["ln_w"], A["ln_b"], A["wqkv"], A["bqkv"], A["wout"], A["bout"], M["ln_w"], M["ln_b"], M["w1"], M["b1"], M["w2"], M["b2"]))
+    refs.append((A, M))
+
+
+def eight():
+    for A, M in refs:
+        ops.encoder_attn(y, A["ln_w"], A["ln_b"], A["wqkv"], A["bqkv"], A["wout"], A["bout"], B, S, 4, 1e-5)
+        ops.encoder_mlp(y, M["ln_w"], M["ln_b"], M["w1"], M["b1"], M["w2"], M["b2"], 1e-5)
+
+
+y.copy_(x)
+print(f"4 layers, eight launches T={T}: {timeit(eight, 20):8.1f} us", flush=True)
+y.copy_(x)
+print(f"4 layers, one launch    T={T}: {timeit(lambda: ops.encoder_stack(y, lays, B, S, 4, 1e-5), 20):8.1f} us", flush=True)

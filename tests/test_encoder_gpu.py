@@ -139,3 +139,56 @@ def test_engine_fused_and_per_op_encoder_agree():
         finally:
             eng.FUSED_MIN_TOKENS = keep
     assert torch.equal(fused, per_op), f"max |diff| {(fused - per_op).abs().max().item():.3g}"
+
+
+@pytest.mark.parametrize("B,S,L", [(512, 50, 4), (7, 50, 4), (3, 17, 2), (64, 56, 3), (1, 1, 1), (33, 50, 6)])
+def test_encoder_stack_equals_the_per_layer_kernels(B, S, L):
+    """The whole encoder in one launch (enc_stack_kernel, csrc/encoder.hip: a workgroup carries its two images through
+    every layer) against encoder_attn + encoder_mlp called layer by layer: the SAME BITS, at the benchmark's batch, at
+    odd batches (a last workgroup with one image), short sequences and the longest one it takes (2 S = 112 rows);
+    launched three times (the residual rows cross between the halves through memory: a missing fence would show as
+    rare stale rows)."""
+    from vit_amd import ops
+    dev = torch.device("cuda:0")
+    E, H, hidden, eps = 256, 4, 1024, 1e-5
+    layers, ref_layers = [], []
+    for li in range(L):
+        A, M = _attn_weights(E, dev, seed=10 * li + 1), _mlp_weights(E, hidden, dev, seed=10 * li + 2)
+        layers.append((A["ln_w"], A["ln_b"], A["wqkv"], A["bqkv"], A["wout"], A["bout"], M["ln_w"], M["ln_b"], M["w1"], M["b1"],
+                       M["w2"], M["b2"]))
+        ref_layers.append((A, M))
+    x = (torch.randn(B * S, E, generator=torch.Generator().manual_seed(B + S + L)) * 1.5 + 0.3).to(dev)
+    want = x.clone()
+    for A, M in ref_layers:
+        ops.encoder_attn(want, A["ln_w"], A["ln_b"], A["wqkv"], A["bqkv"], A["wout"], A["bout"], B, S, H, eps)
+        ops.encoder_mlp(want, M["ln_w"], M["ln_b"], M["w1"], M["b1"], M["w2"], M["b2"], eps)
+    assert torch.isfinite(want).all() and (want - x).abs().max() > 0.1
+    for rep in range(3):
+        got = x.clone()
+        ops.encoder_stack(got, layers, B, S, H, eps)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"rep {rep}: max diff {(got - want).abs().max().item():.3g}"
+    with pytest.raises(ValueError):
+        ops.encoder_stack(torch.zeros(2 * 57, E, device=dev), layers, 2, 57, H, eps)     # 2 S > 112
+
+
+def test_engine_encoder_stack_and_per_layer_agree():
+    """Through the engine at a batch above the fusion threshold: one launch for the stack vs eight launches: same bits."""
+    from vit_amd.model import CNNViTHybrid
+    from vit_amd.synth import micro_doppler_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    m = CNNViTHybrid(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, backbone="resnet18").to(dev).eval()
+    x = micro_doppler_batch(12, seed=9).to(dev)
+    eng = m.engine
+    keep = eng.FUSED_MIN_TOKENS
+    eng.FUSED_MIN_TOKENS = 0
+    try:
+        with torch.no_grad():
+            assert eng.fused_stack
+            one = m(x).clone()
+            eng.fused_stack = False
+            eight = m(x).clone()
+    finally:
+        eng.FUSED_MIN_TOKENS, eng.fused_stack = keep, True
+    assert torch.equal(one, eight)

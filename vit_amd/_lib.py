@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 20
+ABI_VERSION = 21
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "rvit_layernorm_fwd": ([P, I, L, P, P, P, I, L, P, P, L, I, F, P], c_int),
     "rvit_encoder_mlp_fwd": ([P, P, P, F, P, P, P, P, L, I, I, I, P], c_int),
     "rvit_encoder_attn_fwd": ([P, P, P, F, P, P, P, P, I, I, I, I, P], c_int),
+    "rvit_encoder_stack_fwd": ([P, P, I, F, I, I, I, I, I, P], c_int),
     "rvit_layernorm_bwd": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P, L, P], c_int),
     "rvit_layernorm_bwd_drop": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P, L, F, U64, P], c_int),
     "rvit_attn_fwd": ([P, P, P, I, I, I, L, L, F, F, U64, P], c_int),

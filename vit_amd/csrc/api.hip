@@ -318,6 +318,11 @@ int rvit_encoder_attn_fwd(float* x, const float* gamma, const float* beta, float
   return rvit_encoder_attn_impl(x, gamma, beta, eps, wqkv, bqkv, wout, bout, B, S, E, H, (hipStream_t)stream);
 }
 
+int rvit_encoder_stack_fwd(float* x, const void* const* layer_params, int n_layers, float eps, int B, int S, int E, int H,
+                           int hidden, void* stream) {
+  return rvit_encoder_stack_impl(x, layer_params, n_layers, eps, B, S, E, H, hidden, (hipStream_t)stream);
+}
+
 int rvit_attn_fwd_fp8(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out_s, int B, int S, int H, int64_t ldq,
                       float scale, void* stream) {
   return rvit_attn_fwd_fp8_impl(qkv, out_q, ldo, out_s, B, S, H, ldq, scale, (hipStream_t)stream);

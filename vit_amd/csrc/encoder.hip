@@ -139,22 +139,25 @@ __device__ __forceinline__ void ln_to_lds(const float* __restrict__ x, const flo
 // the next step's takes the other half of the same 128-byte lines, and issued back to back the second one hits in
 // the vector L1; a step apart (8 waves x 8 KB of lines in flight against 32 KB of L1) it fetched every line twice.
 template <int MT>
-__global__ __launch_bounds__(EN_THREADS) void enc_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float eps,
-                                                             const bf16* __restrict__ w1, const float* __restrict__ b1,
-                                                             const bf16* __restrict__ w2, const float* __restrict__ b2,
-                                                             long T, int rows_per_wg, int hidden) {
+__device__ __forceinline__ void enc_mlp_body(float* __restrict__ x, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float eps, const bf16* __restrict__ w1,
+                                             const float* __restrict__ b1, const bf16* __restrict__ w2,
+                                             const float* __restrict__ b2, const long row0, const int nrows, int hidden) {
   constexpr int ROWS = MT * 16;
   constexpr int RING = 4;
+  // the dynamic LDS is named here, not passed in: through a generic pointer parameter the non-inlined calls of the
+  // stack kernel turned every LDS access into a flat one (2.3x slower)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA = smem;
   char* const sH = smem + ROWS * 512;
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // The thread index passes through an empty asm: inside the stack kernel's layer loop nothing derived from it can be
+  // hoisted out of the loop and kept alive across the OTHER half (that cost 157 spilled registers); each half keeps
+  // the register allocation it has as a kernel of its own.
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const long row0 = (long)blockIdx.x * rows_per_wg;
-  const long left = T - row0;
-  const int nrows = left < rows_per_wg ? (int)left : rows_per_wg;
 
   // weight stream of this wave: step s < 8 of chunk j: linear1 rows j*256 + 32 wave + 16 nt + fr, K offset 32 s;
   // step s >= 8: linear2 rows 32 wave + 16 nt + fr, K offset j*256 + 32 (s - 8)
@@ -313,6 +316,18 @@ __global__ __launch_bounds__(EN_THREADS) void enc_mlp_kernel(float* __restrict__
 }
 
 template <int MT>
+__global__ __launch_bounds__(EN_THREADS) void enc_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             const bf16* __restrict__ w1, const float* __restrict__ b1,
+                                                             const bf16* __restrict__ w2, const float* __restrict__ b2,
+                                                             long T, int rows_per_wg, int hidden) {
+  const long row0 = (long)blockIdx.x * rows_per_wg;
+  const long left = T - row0;
+  const int nrows = left < rows_per_wg ? (int)left : rows_per_wg;
+  enc_mlp_body<MT>(x, gamma, beta, eps, w1, b1, w2, b2, row0, nrows, hidden);
+}
+
+template <int MT>
 int launch_mlp(float* x, const float* gamma, const float* beta, float eps, const bf16* w1, const float* b1,
                const bf16* w2, const float* b2, long T, int rows_per_wg, int hidden, hipStream_t st) {
   constexpr int ROWS = MT * 16;
@@ -464,11 +479,10 @@ __global__ __launch_bounds__(256) void attn16_kernel(const bf16* __restrict__ qk
   }
 }
 
-__global__ __launch_bounds__(EN_THREADS) void enc_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float eps,
-                                                              const bf16* __restrict__ wqkv, const float* __restrict__ bqkv,
-                                                              const bf16* __restrict__ wout, const float* __restrict__ bout,
-                                                              int B, int S, float scale_log2e) {
+__device__ __forceinline__ void enc_attn_body(float* __restrict__ x, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, float eps, const bf16* __restrict__ wqkv,
+                                              const float* __restrict__ bqkv, const bf16* __restrict__ wout,
+                                              const float* __restrict__ bout, const int img0, int B, int S, float scale_log2e) {
   constexpr int H = EN_E / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sA = smem;
@@ -477,10 +491,11 @@ __global__ __launch_bounds__(EN_THREADS) void enc_attn_kernel(float* __restrict_
   char* const sO = sK + 128 * 128;
   char* const sVt = sO + 128 * 128;
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int t = threadIdx.x;   // opaque, as in enc_mlp_body
+  asm volatile("" : "+v"(t));
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
-  const int img0 = blockIdx.x * 2;
   const int n_img = B - img0 < 2 ? B - img0 : 2;
   const long row0 = (long)img0 * S;
   const int nrows = n_img * S;
@@ -643,7 +658,98 @@ __global__ __launch_bounds__(EN_THREADS) void enc_attn_kernel(float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(EN_THREADS) void enc_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              const bf16* __restrict__ wqkv, const float* __restrict__ bqkv,
+                                                              const bf16* __restrict__ wout, const float* __restrict__ bout,
+                                                              int B, int S, float scale_log2e) {
+  enc_attn_body(x, gamma, beta, eps, wqkv, bqkv, wout, bout, (int)blockIdx.x * 2, B, S, scale_log2e);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The WHOLE encoder stack in one launch (round 3).  Both halves of a layer give a workgroup whole images (attention
+// mixes tokens of one image only), and at 2 S <= 112 the mlp half takes the same 2 S consecutive token rows: the
+// workgroup that owns images 2b, 2b + 1 needs nothing from any other workgroup from the first LayerNorm to the last
+// residual add.  So the eight launches of a four-layer encoder become one: between the halves the fp32 residual rows
+// go to memory and come straight back from the L2 of the CU's XCD (written microseconds earlier) instead of being
+// drained to HBM behind a kernel boundary and fetched again, and the seven drain / launch gaps disappear.  The
+// arithmetic is the two bodies above, unchanged: same bits as the two-kernel path and as the per-op path.
+// Between the halves: the stores of the finishing half must be visible to every wave of the workgroup: release +
+// barrier + acquire at WORKGROUP scope (the waves of a workgroup share their CU's vector L1, which is write-through, so
+// this is a wait for the stores plus the barrier; agent-scope fences write back and invalidate the XCD's L2 at every
+// boundary and made the launch 2.3x slower than the eight kernels it replaces).
+constexpr int EN_MAX_LAYERS = 16;
+struct EncLayerPtrs {
+  const float *g1, *be1; const bf16* wqkv; const float* bqkv; const bf16* wout; const float* bout;
+  const float *g2, *be2; const bf16* w1; const float* b1; const bf16* w2; const float* b2;
+};
+struct EncStackPtrs { EncLayerPtrs L[EN_MAX_LAYERS]; };
+
+template <int MT>
+__global__ __launch_bounds__(EN_THREADS) void enc_stack_kernel(float* __restrict__ x, const EncStackPtrs P, int n_layers,
+                                                               float eps, int B, int S, int hidden, float scale_log2e) {
+  const int img0 = (int)blockIdx.x * 2;
+  const int n_img = B - img0 < 2 ? B - img0 : 2;
+  const long row0 = (long)img0 * S;
+  const int nrows = n_img * S;
+#pragma unroll 1
+  for (int l = 0; l < n_layers; ++l) {
+    const EncLayerPtrs& q = P.L[l];
+    enc_attn_body(x, q.g1, q.be1, eps, q.wqkv, q.bqkv, q.wout, q.bout, img0, B, S, scale_log2e);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    enc_mlp_body<MT>(x, q.g2, q.be2, eps, q.w1, q.b1, q.w2, q.b2, row0, nrows, hidden);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
+template <int MT>
+int launch_stack(float* x, const EncStackPtrs& P, int n_layers, float eps, int B, int S, int hidden, hipStream_t st) {
+  constexpr int LDS = EN_ATTN_LDS > 2 * MT * 16 * 512 ? EN_ATTN_LDS : 2 * MT * 16 * 512;
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)enc_stack_kernel<MT>}, LDS, "encoder_stack")) return rc;
+  hipLaunchKernelGGL((enc_stack_kernel<MT>), dim3((unsigned)((B + 1) / 2)), dim3(EN_THREADS), LDS, st, x, P, n_layers, eps, B, S,
+                     hidden, 0.125f * 1.44269504088896340736f);
+  RVIT_CHECK_LAUNCH("encoder_stack");
+  return RVIT_OK;
+}
+
 }  // namespace
+
+// layer_ptrs: HOST array of 12 device pointers per layer, in the order of EncLayerPtrs (norm1 weight, bias, in_proj
+// weight, bias, out_proj weight, bias, norm2 weight, bias, linear1 weight, bias, linear2 weight, bias)
+int rvit_encoder_stack_impl(float* x, const void* const* layer_ptrs, int n_layers, float eps, int B, int S, int E, int H,
+                            int hidden, hipStream_t st) {
+  RVIT_CHECK_ARG(x && layer_ptrs, "encoder_stack: null operand");
+  RVIT_CHECK_ARG(n_layers >= 0 && n_layers <= EN_MAX_LAYERS, "encoder_stack: %d layers (at most %d)", n_layers, EN_MAX_LAYERS);
+  RVIT_CHECK_ARG(E == EN_E && H * 64 == E, "encoder_stack: built for embedding width %d with %d heads of 64, got E=%d H=%d",
+                 EN_E, EN_E / 64, E, H);
+  RVIT_CHECK_ARG(S >= 1 && 2 * S <= 112, "encoder_stack: sequence length %d outside 1..56 (two images per workgroup, at most 112 rows)", S);
+  RVIT_CHECK_ARG(hidden > 0 && hidden % EN_HC == 0, "encoder_stack: hidden width %d must be a multiple of %d", hidden, EN_HC);
+  RVIT_CHECK_ARG(B >= 0 && B < (1 << 30), "encoder_stack: bad batch %d", B);
+  RVIT_CHECK_ARG(rvit_aligned16(x), "encoder_stack: x must be 16-byte aligned");
+  EncStackPtrs P{};
+  for (int l = 0; l < n_layers; ++l) {
+    const void* const* q = layer_ptrs + 12 * l;
+    for (int k = 0; k < 12; ++k) RVIT_CHECK_ARG(q[k] && rvit_aligned16(q[k]), "encoder_stack: layer %d operand %d is null or not 16-byte aligned", l, k);
+    P.L[l] = EncLayerPtrs{(const float*)q[0], (const float*)q[1], (const bf16*)q[2], (const float*)q[3], (const bf16*)q[4],
+                          (const float*)q[5], (const float*)q[6], (const float*)q[7], (const bf16*)q[8], (const float*)q[9],
+                          (const bf16*)q[10], (const float*)q[11]};
+  }
+  if (B == 0 || n_layers == 0) return RVIT_OK;
+  switch ((2 * S + 15) / 16) {
+    case 1: return launch_stack<1>(x, P, n_layers, eps, B, S, hidden, st);
+    case 2: return launch_stack<2>(x, P, n_layers, eps, B, S, hidden, st);
+    case 3: return launch_stack<3>(x, P, n_layers, eps, B, S, hidden, st);
+    case 4: return launch_stack<4>(x, P, n_layers, eps, B, S, hidden, st);
+    case 5: return launch_stack<5>(x, P, n_layers, eps, B, S, hidden, st);
+    case 6: return launch_stack<6>(x, P, n_layers, eps, B, S, hidden, st);
+    default: return launch_stack<7>(x, P, n_layers, eps, B, S, hidden, st);
+  }
+}
 
 int rvit_encoder_mlp_impl(float* x, const float* gamma, const float* beta, float eps, const void* w1, const float* b1,
                           const void* w2, const float* b2, long T, int E, int hidden, int rows_per_wg, hipStream_t st) {

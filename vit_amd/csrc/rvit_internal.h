@@ -155,6 +155,8 @@ int rvit_encoder_mlp_impl(float* x, const float* gamma, const float* beta, float
 int rvit_encoder_attn_impl(float* x, const float* gamma, const float* beta, float eps, const void* wqkv,
                            const float* bqkv, const void* wout, const float* bout, int B, int S, int E, int H,
                            hipStream_t st);
+int rvit_encoder_stack_impl(float* x, const void* const* layer_ptrs, int n_layers, float eps, int B, int S, int E, int H,
+                            int hidden, hipStream_t st);
 int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, long ldq, long ldo, float scale,
                        float drop_p, uint64_t drop_seed, hipStream_t st);
 int rvit_attn_fwd_fp8_impl(const void* qkv, uint8_t* out_q, long ldo, uint8_t* out_s, int B, int S, int H, long ldq,

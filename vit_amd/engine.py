@@ -58,6 +58,7 @@ class Engine:
         # fused encoder-layer kernels where the shape allows (RVIT_ENCODER_FUSED=0: the per-op path, for A/B runs)
         self.fused_encoder = os.environ.get("RVIT_ENCODER_FUSED", "1") != "0"
         self.FUSED_MIN_TOKENS = int(os.environ.get("RVIT_FUSED_MIN_TOKENS", "12800"))
+        self.fused_stack = os.environ.get("RVIT_ENCODER_STACK", "1") != "0"   # all layers in one launch (A/B: 0 = per layer)
         self.graph_max_batch = 0
 
     def set_precision(self, precision: str) -> None:
@@ -349,6 +350,24 @@ class Engine:
             ops.gemm(b["ln"], L["fc1_w"], b["hid"], bias=L["fc1_b"], act="gelu")
             ops.gemm(b["hid"], L["fc2_w"], x2, bias=L["fc2_b"], residual=x2)
 
+    def _encoder(self, P, b, B) -> None:
+        """`self.transformer(x)` (train_vit.py:163) on b["x"].  Where the fused kernels apply and every LayerNorm shares
+        one eps, the whole stack is ONE launch (csrc/encoder.hip enc_stack_kernel: a workgroup keeps its two images from
+        the first LayerNorm to the last residual add; same bits as the per-layer kernels), else layer by layer."""
+        m = self.m
+        E, S, H = m.embed_dim, m.num_patches + 1, m.num_heads
+        layers = P["layers"]
+        if (self.precision != "mxfp8" and self.fused_encoder and self.fused_stack and layers
+                and B * S >= self.FUSED_MIN_TOKENS
+                and ops.encoder_stack_supported(E, H, S, layers[0]["fc1_w"].shape[0], len(layers))
+                and len({L["eps1"] for L in layers} | {L["eps2"] for L in layers}) == 1):
+            ops.encoder_stack(b["x"].view(B * S, E),
+                              [(L["ln1_w"], L["ln1_b"], L["qkv_w"], L["qkv_b"], L["out_w"], L["out_b"], L["ln2_w"], L["ln2_b"],
+                                L["fc1_w"], L["fc1_b"], L["fc2_w"], L["fc2_b"]) for L in layers], B, S, H, layers[0]["eps1"])
+            return
+        for L in layers:
+            self._encoder_layer(L, b, B)
+
     @torch.no_grad()
     def infer(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
         m = self.m
@@ -374,8 +393,7 @@ class Engine:
             ops.conv2d_tokens(b["img"], P["pe_w"], xs, P["pos"], kh=16, kw=1, stride=16, pad=0, seg_len=64, ho=14,
                               wo=14, bias=P["pe_b"])
         ops.embed_cls(P["cls"], P["pos"], xs)
-        for L in P["layers"]:
-            self._encoder_layer(L, b, B)
+        self._encoder(P, b, B)
         cls_rows = xs.view(B, S * E)[:, :E]
         if features_only:
             out = torch.empty(B, E, dtype=torch.float32, device=x.device)

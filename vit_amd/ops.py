@@ -548,6 +548,44 @@ def encoder_attn(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, wqkv:
     return x
 
 
+def encoder_stack(x: torch.Tensor, layers, B: int, S: int, H: int, eps: float = 1e-5) -> torch.Tensor:
+    """Every layer of the pre-LN encoder in ONE launch, in place on x (f32 [B*S,256] contiguous).  `layers`: per layer the
+    twelve tensors (norm1 w, b, in_proj w, b, out_proj w, b, norm2 w, b, linear1 w, b, linear2 w, b); bf16 weights, f32
+    vectors.  Same bits as encoder_attn + encoder_mlp per layer."""
+    import ctypes
+    flat = [t for lay in layers for t in lay]
+    _need_cuda(x, *flat)
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_contiguous() or x.shape[0] != B * S:
+        raise ValueError("encoder_stack: x must be a contiguous float32 [B*S, E] tensor")
+    E = x.shape[1]
+    nl = len(layers)
+    if nl == 0:
+        return x
+    hidden = layers[0][8].shape[0]
+    if not encoder_stack_supported(E, H, S, hidden, nl):
+        raise ValueError(f"encoder_stack: E={E} H={H} S={S} hidden={hidden} layers={nl} not supported")
+    for lay in layers:
+        if len(lay) != 12:
+            raise ValueError("encoder_stack: twelve tensors per layer")
+        g1, be1, wqkv, bqkv, wout, bout, g2, be2, w1, b1, w2, b2 = lay
+        for w, shp in ((wqkv, (3 * E, E)), (wout, (E, E)), (w1, (hidden, E)), (w2, (E, hidden))):
+            if w.dtype != BF16 or tuple(w.shape) != shp or not w.is_contiguous():
+                raise ValueError(f"encoder_stack: weight of shape {tuple(w.shape)} must be contiguous bf16 {shp}")
+        for v, n in ((g1, E), (be1, E), (bqkv, 3 * E), (bout, E), (g2, E), (be2, E), (b1, hidden), (b2, E)):
+            _vec_f32(v, n, "encoder_stack: vector operand")
+    table = (ctypes.c_void_p * (12 * nl))(*[t.data_ptr() for t in flat])
+    T = B * S
+    with _Span("encoder_stack", nl * (2 * T * E * 4 * E + 4 * B * H * S * S * 64 + 4 * T * E * hidden),
+               8 * T * E + nl * (8 * E * E + 4 * E * hidden)):
+        check(_lib.load().rvit_encoder_stack_fwd(x.data_ptr(), table, nl, float(eps), B, S, E, H, hidden, _stream()),
+              "rvit_encoder_stack_fwd")
+    return x
+
+
+def encoder_stack_supported(E: int, H: int, S: int, hidden: int, n_layers: int) -> bool:
+    return E == 256 and H == 4 and 1 <= S <= 56 and hidden > 0 and hidden % 256 == 0 and 1 <= n_layers <= 16
+
+
 def encoder_attn_supported(E: int, H: int, S: int) -> bool:
     return E == 256 and H == 4 and 1 <= S <= 64
 
