@@ -1,36 +1,39 @@
-// Direct 3x3 / stride 1 / pad 1 NHWC convolution on the eight-wave, four-phase skeleton of gemm8p.hip (round 3).
+// Direct 3x3 / stride 1 / pad 1 NHWC convolution on the eight-wave staggered skeleton of gemm8p.hip (round 3).
 //
 // Replaces conv3x3.hip's generic kernel on the 3x3 stride-1 convs of resnet layers 2-4 (`self.cnn_backbone(x)[-1]`,
-// train_vit.py:87,145-146) and, with `flip`, their input gradients.  Same products in the same order (64-channel slice
-// -> tap -> two 32-deep MFMA steps), so the results are BIT-IDENTICAL to conv3x3.hip and to the implicit-GEMM kernel.
+// train_vit.py:87,145-146) and, with `flip`, their input gradients, wherever its tiles fill whole rounds of the CUs
+// (rvit_conv3x3_p8_pays).  Same products in the same order (64-channel slice -> tap -> two 32-deep MFMA steps), so the
+// results are BIT-IDENTICAL to conv3x3.hip and to the implicit-GEMM kernel.
 //
 // Why.  conv3x3.hip runs two 8-wave workgroups per CU, one workgroup barrier per tap (16 MFMAs per wave between
 // barriers, 0.75 fragment reads per MFMA) and stops at 0.33-0.36 of the bf16 MFMA peak: its waves run their LDS-read
-// and MFMA phases in lockstep (profiles/r02_conv3x3_notes.txt).  gemm8p.hip's schedule keeps the matrix pipe ~87 % busy
-// inside its K loop with ONE workgroup per CU: a wave owns a tall tile (here 7 x 4 fragments = 112 pixels x 64 channels,
-// 56 MFMAs per tap fed by 22 fragment reads = 0.39 per MFMA), the tap is cut into four phases of one quadrant each,
-// and waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave multiplies while its partner reads.
+// and MFMA phases in lockstep (profiles/r02_conv3x3_notes.txt).  Here ONE workgroup owns the CU: a wave owns a tall tile
+// (7 x 4 fragments = 112 pixels x 64 channels, 56 MFMAs per tap fed by 22 fragment reads = 0.39 per MFMA), and waves
+// 4-7 run one barrier behind waves 0-3 (gemm8p.hip's stagger), so on every SIMD one wave multiplies while its partner
+// reads and issues DMA.
 //
 // What differs from the GEMM: the pixel operand is not staged per K tile.  The zero-padded input rows the tile's
 // pixels touch ("padded row" space of conv3x3.hip: one shared zero row between images) are RESIDENT in LDS per
 // 64-channel slice, double-buffered; the nine taps read them at row offsets kh*(W+2)+kw.  The next slice streams in
-// one 1 KB piece per wave per tap (taps 0-7) beside the weight half-tiles, which are the only per-tap DMA:
-//   phase 1: read B0 (4 reads, retired before the barrier), A0 (8)   one patch piece of the next slice   multiply (A0,B0)
-//   phase 2: read B1 (4)                                             stage B0 of tap t+2                 multiply (A0,B1)
-//   phase 3: read A1 (6)                                                                                 multiply (A1,B1)
-//   phase 4: -                          wait vmcnt(1 + 2 BL)         stage B1 of tap t+2                 multiply (A1,B0)
-// (A0 = pixel fragments 0-3, A1 = 4-6 of the wave; B half h = channels wc*64 + h*32 + [0,32); BL = DMA instructions
-// per wave and weight half: 2 for 256 output channels per workgroup, 1 for 128).  Hazards as in gemm8p.hip: a weight
-// half is read one phase or more after the counted wait that retired it and re-staged two phases after its last read
-// (B0: one phase, its reads are retired before the reading phase's first barrier); the patch buffer of slice c+1 was
-// last read in tap 8 of slice c-1 and is complete after tap 8 of slice c (pieces are issued in taps 0-7, tap 8's
-// counted wait retires the last one, and both wave groups pass a barrier before the first read).  Every tap issues the
-// same number of DMA instructions (a piece that does not exist goes from the zero page to a dummy LDS slot), so the
-// counted wait is a constant.
+// one 1 KB piece per wave per tap (taps 0-7) beside the weight tile (TN x 64, two halves), the only per-tap DMA.
+// A tap is two phases (gemm8p.hip's four phases of one quadrant each measured 7-10 % slower here: profiles/
+// r03_conv3x3_p8_notes.txt):
+//   phase 1: read both weight halves (8 reads, retired before the barrier) and pixel fragments 0-3 (8)      32 MFMAs
+//   phase 2: read pixel fragments 4-6 (6); one patch piece of the next slice; stage the weight tile of tap t+2;
+//            wait vmcnt(1 + 2 BL)                                                                            24 MFMAs
+// (BL = DMA instructions per wave and weight half: 2 for 256 output channels per workgroup, 1 for 128.)  Hazards.  RAW:
+// weight tile t+2 is staged in phase 2 of tap t, retired by the counted wait of tap t+1 (which leaves that tap's piece
+// and tile t+3 in flight) and read in tap t+2; both wave groups pass a barrier between their wait and the other
+// group's first read.  WAR: a tile's reads are retired before the first barrier of its phase 1 (lgkmcnt(8) behind
+// reads issued weights-first), for the trailing group that is the barrier the leading group passes before it
+// re-stages the slot in phase 2.  The patch buffer of slice c+1 was last read in tap 8 of slice c-1 and is complete
+// after tap 8 of slice c (pieces are issued in taps 0-7, tap 8's counted wait retires the last one).  Every tap issues
+// the same number of DMA instructions (a piece that does not exist goes from the zero page to a dummy LDS slot), so
+// the counted wait is a constant.
 //
 // Tiles are `tile_len` CONSECUTIVE output pixels x TN channels; wave row r owns pixels [r*ppw, (r+1)*ppw) of the tile
-// (ppw <= 112).  The host picks tile_len so that the tile count is a whole number of rounds over the CUs (B=512: one
-// image / half an image / four images per tile on the 14- / 28- / 7-wide maps: exactly 2 / 4 / 1 rounds of 256
+// (ppw <= 112).  The host picks tile_len so that the tile count is a whole number of rounds over the CUs (B=512: half
+// an image / one image / four images per tile on the 28- / 14- / 7-wide maps: exactly 4 / 2 / 1 rounds of 256
 // workgroups); the result does not depend on that choice.
 #include <stdlib.h>
 
