@@ -498,9 +498,9 @@ def main():
             roofline["algorithmic_bytes_per_launch"] = round(kernels[roofline["kernel"]]["bytes"] / kernels[roofline["kernel"]]["launches"])
             # HBM traffic of the same kernel from the committed PMC passes (profiles/, same command and batch).  The
             # file carries the hash of the kernel's source: a traffic figure measured on another version of the kernel
-            # is not replayed (traffic stays null until scripts/profile_r02.sh is run again).
+            # is not replayed (traffic stays null until scripts/profile_r03.sh + make_pmc_json_r03.py are run again).
             here = os.path.dirname(os.path.abspath(__file__))
-            pmc = os.path.join(here, "bench_pmc_r02.json")
+            pmc = os.path.join(here, "bench_pmc_r03.json")
             if os.path.exists(pmc):
                 import hashlib
                 with open(pmc) as fh:
@@ -509,7 +509,7 @@ def main():
                 same_src = os.path.isfile(src) and hashlib.sha256(open(src, "rb").read()).hexdigest() == t.get("kernel_source_sha256")
                 if t.get("kernel") == roofline["kernel"] and t.get("batch_per_gpu") == B and same_src:
                     roofline["traffic"] = t["traffic_bytes_per_launch"]
-                    roofline["traffic_source"] = ("bench_pmc_r02.json = profiles/r02_pmc_traffic.json (rocprofv3 --pmc "
+                    roofline["traffic_source"] = ("bench_pmc_r03.json = profiles/r03_pmc_traffic.json (rocprofv3 --pmc "
                                                   "FETCH_SIZE x2 + WRITE_SIZE, per launch, same command, same kernel source)")
         frames = world * B * args.steps
         value = frames / dt

@@ -262,7 +262,9 @@ def gemm_mx(a_q: torch.Tensor, a_s: torch.Tensor, w_q: torch.Tensor, w_s: torch.
 @functools.lru_cache(maxsize=256)
 def _conv3x3_name(B: int, H: int, W: int, Cin: int, Cout: int) -> str:
     code = _lib.load().rvit_conv3x3_kernel(B, H, W, Cin, Cout)
-    return ("conv2d_gather", "conv3x3_direct", "conv3x3_c64", "conv3x3_c256", "conv3x3_p8")[code]
+    if code == 4:    # conv3x3_p8_kernel<256> / <128> are two kernels (rocprofv3 lists them apart): so do the spans
+        return "conv3x3_p8_256" if Cout % 256 == 0 else "conv3x3_p8_128"
+    return ("conv2d_gather", "conv3x3_direct", "conv3x3_c64", "conv3x3_c256")[code]
 
 
 def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
@@ -294,7 +296,8 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
         if tile == 0:
             name = _conv3x3_name(B, H, W, Cpix, Cout)
         elif 10 <= tile <= 19:
-            name = {14: "conv3x3_c64", 15: "conv3x3_c256", 18: "conv3x3_c256", 19: "conv3x3_p8"}.get(tile, "conv3x3_direct")
+            name = {14: "conv3x3_c64", 15: "conv3x3_c256", 18: "conv3x3_c256",
+                    19: "conv3x3_p8_256" if Cout % 256 == 0 else "conv3x3_p8_128"}.get(tile, "conv3x3_direct")
     with _Span(name, 2 * B * Ho * Wo * Cout * true_k,
                _nbytes(x, w, out, residual)):
         check(lib.rvit_conv2d_fwd_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cpix, seg, kh, kw, stride,
