@@ -235,11 +235,13 @@ __device__ __forceinline__ void drop_mult8(const DropKey& k, uint32_t idx0, floa
   }
 }
 
+// Two floats -> one dword of two bf16 (round to nearest even), `lo` in the low half.  Written as a VECTOR conversion:
+// that is one v_cvt_pk_bf16_f32; two scalar casts stored into a union compile to two conversions + a shift + an or
+// (four vector instructions per pair; found in round 3 in the ISA of the stem entry's epilogue).  Same rounding.
+typedef __bf16 rvit_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rvit_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  union { bf16 h[2]; uint32_t u; } r;
-  r.h[0] = (bf16)lo;
-  r.h[1] = (bf16)hi;
-  return r.u;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(rvit_f32x2{lo, hi}, rvit_bf16x2));
 }
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }

@@ -29,8 +29,15 @@ __device__ uint4 g_zero_page_c1[4];
 #ifdef RVIT_C1_STAMPS   // diagnosis build only: s_memtime per workgroup phase (scripts/c1_stamps.py)
 __device__ unsigned long long g_c1_stamps[16384 * 8];
 #define C1_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_c1_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// rolling-band kernel: per-phase cycle sums over the bands of a workgroup (wave 0)
+#define C1R_DECL unsigned long long c1r_t = __builtin_amdgcn_s_memtime(), c1r_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define C1R_LAP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); c1r_acc[k] += n_ - c1r_t; c1r_t = n_; } while (0)
+#define C1R_FLUSH do { if (threadIdx.x == 0 && blockIdx.x < 16384) for (int k_ = 0; k_ < 8; ++k_) g_c1_stamps[blockIdx.x * 8 + k_] = c1r_acc[k_]; } while (0)
 #else
 #define C1_STAMP(k) do {} while (0)
+#define C1R_DECL do {} while (0)
+#define C1R_LAP(k) do {} while (0)
+#define C1R_FLUSH do {} while (0)
 #endif
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -260,6 +267,266 @@ __global__ __launch_bounds__(512, 4) void conv1_pool_kernel(const void* __restri
   C1_STAMP(5);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Rolling-band form (round 3; fp32 NCHW input + ReLU: what eval-mode inference runs).  The band kernel above fetches
+// 1.84x its input (the 15-row patches of neighbouring bands overlap by 7 rows: profiles/r02_pmc_traffic.json), recomputes
+// every fifth conv row, runs load -> MFMA -> LDS map -> pool strictly in sequence inside a workgroup and needs 80 KB of
+// LDS for the conv-out map.  Here a workgroup walks DOWN an image (or a segment of it) two pooled rows at a time:
+//   * the packed bf16 rows live in a 24-row LDS ring; a band needs 13 rows (conv rows c0 .. c0+3), 8 of them new.  The
+//     new rows of band k+1 are requested (fp32, three planes) before the MFMAs of band k and written into the ring
+//     after its stores, so their HBM latency hides behind the band; one workgroup barrier per band.  Every input row
+//     is fetched once per segment;
+//   * wave w owns conv columns 14w-1 .. 14w+14 of every row (16 columns = one MFMA block; 15 of them are the windows
+//     of pooled pixels 7w .. 7w+6; 14 % more columns than the map has instead of 25 % more rows): the vertical
+//     maximum is a register maximum, the horizontal one two DPP row shifts, and the conv row shared with the next band
+//     (row c0+3 = 2*py+3) is carried in registers as packed bf16 -> no conv row is computed twice, no LDS map;
+//   * maxima run on the bf16 BITS (v_pk_max_i16 with a floor of 0 = ReLU, as the band kernel's pool phase), pooled
+//     pixels leave as 16-byte stores after a v_permlane16_swap between lane rows (gemm8p.hip's epilogue idiom).
+// Same MFMAs in the same kh order, the same fused multiply-add of scale / bias and the same rounding: bit-identical
+// to the band kernel (tests/test_kernels_gpu.py::test_stem_conv1_pool_fused).  74.75 KB LDS, 128 registers: two
+// workgroups per CU whose phases interleave.
+constexpr int RING_ROWS = 24;
+constexpr int RING_BYTES = RING_ROWS * ROW_B;            // 44,544
+constexpr int ROLL_SB_OFF = W_BYTES + RING_BYTES;        // scale[64], bias[64] as floats
+constexpr int ROLL_LDS = ROLL_SB_OFF + 512;              // 74,752
+constexpr int BANDS = HQ / 2;                            // 28 bands of two pooled rows per image
+
+typedef short c1_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t c1_pkmax(uint32_t a, uint32_t b) {
+  c1_s16x2 x, y;
+  __builtin_memcpy(&x, &a, 4);
+  __builtin_memcpy(&y, &b, 4);
+  x = __builtin_elementwise_max(x, y);
+  uint32_t r;
+  __builtin_memcpy(&r, &x, 4);
+  return r;
+}
+
+// NR conv rows x 16 columns x 64 channels: slot0 = ring slot of the first row's kh = 0 input row (wave-uniform).
+// One fragment set and a runtime loop over the kernel rows: the four waves of a SIMD hide each other's LDS round trips.
+// Measured against it on one box (scripts/bench_conv1.py, B = 512, 250 us): two fragment sets with the next kernel
+// row requested before the MFMAs of this one (needs two passes of two rows to fit 128 registers, weights read twice)
+// 263 us; the pixel fragment of row q requested for kernel row kh + 1 right after its last use 255 us; kernel rows
+// unrolled: the compiler hoists every read and spills.  Raised wave priority around the MFMAs (the matrix pipe is the
+// scarce unit, the other waves are doing vector work): -1..2 %, kept.
+template <int NR>
+__device__ __forceinline__ void c1_rows_mfma(const char* sWl, const char* sPl, int slot0, f32x4 (&acc)[NR][4]) {
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[q][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __builtin_amdgcn_sched_barrier(0);   // keeps the epilogue's work from being hoisted over the loop (it spills then)
+  __builtin_amdgcn_s_setprio(2);
+#pragma unroll 1
+  for (int kh = 0; kh < 7; ++kh) {
+    bf16x8 bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sWl + j * 16 * W_PITCH + kh * 64);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      int s = slot0 + 2 * q + kh;
+      s = s >= RING_ROWS ? s - RING_ROWS : s;
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(sPl + s * ROW_B);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af, acc[q][j], 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// scale / bias (one fused multiply-add, as the band kernel) -> packed bf16: pk[q][2j + d] = channels 16j + 4fq + 2d, + 1
+// of conv row q (the scale / bias quad of a channel block is read once for all rows)
+template <int NR>
+__device__ __forceinline__ void c1_affine_pack(const f32x4 (&acc)[NR][4], const float* sSB, int fq, uint32_t (&pk)[NR][8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 s4 = *reinterpret_cast<const float4*>(sSB + 16 * j + 4 * fq);
+    const float4 b4 = *reinterpret_cast<const float4*>(sSB + 64 + 16 * j + 4 * fq);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      pk[q][2 * j] = pack_bf16x2(fmaf(acc[q][j][0], s4.x, b4.x), fmaf(acc[q][j][1], s4.y, b4.y));
+      pk[q][2 * j + 1] = pack_bf16x2(fmaf(acc[q][j][2], s4.z, b4.z), fmaf(acc[q][j][3], s4.w, b4.w));
+    }
+  }
+}
+
+// one pooled row out of three packed conv rows: vertical maximum, horizontal maximum over lanes fr-1, fr, fr+1, floor 0
+// (ReLU); the pooled pixel 7w + i sits in lane fr = 2i + 1.  `edge`: this lane is conv column -1 (outside the map).
+__device__ __forceinline__ void c1_pool_store(const uint32_t (&a)[8], const uint32_t (&b)[8], const uint32_t (&c)[8],
+                                              bool edge_wave, bool edge, bool store_ok, bf16* dst) {
+  uint32_t h[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint32_t m = c1_pkmax(c1_pkmax(a[k], b[k]), c[k]);
+    if (edge_wave) m = edge ? 0u : m;   // wave-uniform: only wave 0 holds column -1
+    const uint32_t l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    const uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+    h[k] = c1_pkmax(c1_pkmax(c1_pkmax(m, l), r), 0u);
+  }
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    // lane rows fq 0 <-> 1, 2 <-> 3 of channel blocks 2pr and 2pr + 1: every lane ends with 8 consecutive channels
+    const auto s0 = __builtin_amdgcn_permlane16_swap(h[4 * pr + 0], h[4 * pr + 2], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(h[4 * pr + 1], h[4 * pr + 3], false, false);
+    uint4 o;
+    o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+    if (store_ok) *reinterpret_cast<uint4*>(dst + 32 * pr) = o;
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void conv1_pool_roll_kernel(const float* __restrict__ xin, const bf16* __restrict__ w,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ bias, bf16* __restrict__ pooled,
+                                                                 int wpi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sW = smem;
+  char* const sP = smem + W_BYTES;
+  float* const sSB = reinterpret_cast<float*>(smem + ROLL_SB_OFF);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x / wpi, seg = blockIdx.x - b * wpi;
+  const int nb = BANDS / wpi;
+  const int band0 = seg * nb;
+  const float* __restrict__ x = xin + (long)b * 3 * 224 * 224;
+
+  // ---- weights by LDS-DMA, scale / bias, zero ring ------------------------------------------------------------------
+  for (int i = wave; i < W_BYTES / 1024; i += 8) glds16(reinterpret_cast<const char*>(w) + i * 1024 + lane * 16, sW + i * 1024);
+  if (t < 64) sSB[t] = scale[t];
+  else if (t < 128) sSB[t] = bias[t - 64];
+  // first window: packed rows p_first .. 2 c0 + 12 (the two extra rows above serve the carried conv row c0 - 1)
+  int c0 = 4 * band0;
+  const int p_first = c0 > 0 ? 2 * c0 - 2 : 0;
+  {
+    const int nrows = 2 * c0 + 12 - p_first + 1;                 // 13 or 15
+    constexpr int UPT = 2;                                       // 15 * 56 = 840 units of 4 pixels x 3 planes
+    float4 v[UPT][3];
+    int dst[UPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int id = t + u * 512;
+      const int r = id / 56, j = id - r * 56;
+      const int p = p_first + r, ir = p - 3;
+      dst[u] = -1;
+      if (r < nrows && (unsigned)ir < 224u) {
+        const float* src = x + (long)ir * 224 + 4 * j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[u][c] = *reinterpret_cast<const float4*>(src + (long)c * 224 * 224);
+        dst[u] = (p % RING_ROWS) * ROW_B + (4 * j + 3) * 8;
+      }
+    }
+    for (int i = t; i < RING_BYTES / 16; i += 512) *reinterpret_cast<uint4*>(sP + i * 16) = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      if (dst[u] < 0) continue;
+      const float p0[4] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w};
+      const float p1[4] = {v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+      const float p2[4] = {v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
+      uint2 px[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        px[e].x = pack_bf16x2(p0[e], p1[e]);
+        px[e].y = pack_bf16x2(p2[e], 0.f);
+      }
+      char* d = sP + dst[u];
+      *reinterpret_cast<uint2*>(d) = px[0];
+      *reinterpret_cast<uint4*>(d + 8) = uint4{px[1].x, px[1].y, px[2].x, px[2].y};
+      *reinterpret_cast<uint2*>(d + 24) = px[3];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // per-lane operand bases: weights rows j*16 + fr, chunk fq of a kernel row; pixels: conv column 14w - 1 + fr reads the
+  // 16 bytes at packed column 2 (14w - 1 + fr) + 2 fq (for w = fr = fq = 0 that is 16 bytes below the ring row: finite
+  // weight bytes that only reach the masked column -1)
+  const char* const sWl = sW + fr * W_PITCH + fq * 16;
+  const char* const sPl = sP + 16 * (14 * wave - 1 + fr + fq);
+  const bool edge = wave == 0 && fr == 0;
+  const bool store_ok = (fr & 1) && fr < 14;
+  const int px = 7 * wave + (fr >> 1);
+  const int ch_off = (fq & 1) * 16 + (fq >> 1) * 8;
+
+  // the band-invariant part of the prefetch unit of this thread: row r of the 8 new rows, quad j
+  const int pf_r = t / 56, pf_j = t - pf_r * 56;
+  const bool pf_thread = t < 8 * 56;
+  const int pf_col = (4 * pf_j + 3) * 8;
+
+  uint32_t T[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) T[k] = 0u;      // above the map: excluded = the ReLU floor
+  if (c0 > 0) {
+    f32x4 a1[1][4];
+    uint32_t t1[1][8];
+    c1_rows_mfma<1>(sWl, sPl, __builtin_amdgcn_readfirstlane((2 * c0 - 2) % RING_ROWS), a1);
+    c1_affine_pack<1>(a1, sSB, fq, t1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) T[k] = t1[0][k];
+  }
+  C1R_DECL;
+
+  // Waves 4-7 run their epilogue one band late: an iteration is {MFMA(k), pack(k), pool(k)} for waves 0-3 and
+  // {pool(k-1), MFMA(k), pack(k)} for waves 4-7 (they carry the band's packed rows over the barrier), so on every SIMD (wave w and w + 4 share one) one wave multiplies while
+  // the other does the vector work of its pooling; without this all eight waves queued for the matrix pipe together
+  // and then for the vector ALU together (stamps: 14.0k cycles per band against 7.2k of MFMA issue per SIMD).
+  const bool late = wave >= 4;
+  uint32_t r[4][8];                           // the band's four conv rows, packed bf16 (what the late group carries)
+  auto pool = [&](int c_band) {
+    bf16* dst = pooled + (((long)b * HQ + (c_band >> 1)) * WQ + px) * 64 + ch_off;
+    c1_pool_store(T, r[0], r[1], wave == 0, edge, store_ok, dst);
+    c1_pool_store(r[1], r[2], r[3], wave == 0, edge, store_ok, dst + WQ * 64);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) T[k] = r[3][k];
+  };
+#pragma unroll 1
+  for (int bi = 0; bi < nb; ++bi, c0 += 4) {
+    const bool has_next = bi + 1 < nb;
+    // ---- request the 8 new rows of the next band -------------------------------------------------------------------
+    float4 nv[3];
+    nv[0] = nv[1] = nv[2] = float4{0.f, 0.f, 0.f, 0.f};
+    const int np = 2 * c0 + 13 + pf_r;                      // packed row; image row np - 3 (>= 10)
+    if (has_next && pf_thread && np - 3 < 224) {
+      const float* src = x + (long)(np - 3) * 224 + 4 * pf_j;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nv[c] = *reinterpret_cast<const float4*>(src + (long)c * 224 * 224);
+    }
+    C1R_LAP(0);
+    if (late && bi > 0) pool(c0 - 4);
+    C1R_LAP(1);
+    // ---- conv rows c0 .. c0 + 3 ---------------------------------------------------------------------------------------
+    {
+      f32x4 acc[4][4];
+      c1_rows_mfma<4>(sWl, sPl, __builtin_amdgcn_readfirstlane((2 * c0) % RING_ROWS), acc);
+      c1_affine_pack<4>(acc, sSB, fq, r);
+    }
+    C1R_LAP(2);
+    if (!late) pool(c0);
+    C1R_LAP(3);
+    // ---- the next band's rows into the ring (rows below the image: zeros) ------------------------------------------
+    if (has_next && pf_thread) {
+      const float p0[4] = {nv[0].x, nv[0].y, nv[0].z, nv[0].w};
+      const float p1[4] = {nv[1].x, nv[1].y, nv[1].z, nv[1].w};
+      const float p2[4] = {nv[2].x, nv[2].y, nv[2].z, nv[2].w};
+      uint2 q4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q4[e].x = pack_bf16x2(p0[e], p1[e]);
+        q4[e].y = pack_bf16x2(p2[e], 0.f);
+      }
+      char* d = sP + (np % RING_ROWS) * ROW_B + pf_col;
+      *reinterpret_cast<uint2*>(d) = q4[0];
+      *reinterpret_cast<uint4*>(d + 8) = uint4{q4[1].x, q4[1].y, q4[2].x, q4[2].y};
+      *reinterpret_cast<uint2*>(d + 24) = q4[3];
+    }
+    C1R_LAP(4);
+    __syncthreads();
+    C1R_LAP(5);
+  }
+  if (late) pool(c0 - 4);
+  C1R_FLUSH;
+}
+
 }  // namespace
 
 int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
@@ -270,6 +537,34 @@ int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale
                  "stem_conv1_pool: operands must be 16-byte aligned");
   RVIT_CHECK_ARG((long)B * (HQ / TP) < 0x7fffffffL, "stem_conv1_pool: batch too large");
   static_assert(CO_BYTES >= W_BYTES + PATCH_BYTES, "conv-out map must cover the staging area it aliases");
+  // fp32 input + ReLU (eval-mode inference): the rolling-band kernel.  Workgroups per image: the fewest of the divisors
+  // of 28 bands that still give two workgroups to every CU (B = 512: one per image, every input row fetched once);
+  // same bits whatever the split, so the choice by batch size keeps batch invariance.  RVIT_CONV1_ROLL=0: A/B runs.
+  static const bool roll = [] { const char* e = getenv("RVIT_CONV1_ROLL"); return !e || atoi(e) != 0; }();
+  if (img_f32 && relu && roll) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        rvit_set_error("stem_conv1_pool: cannot query the device");
+        return RVIT_ELAUNCH;
+      }
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    static const int divisors[6] = {1, 2, 4, 7, 14, 28};
+    int wpi = 28;
+    for (int d : divisors)
+      if ((long)B * d >= 2L * n_cu) { wpi = d; break; }
+    static const int wpi_env = [] { const char* e = getenv("RVIT_CONV1_WPI"); return e ? atoi(e) : 0; }();   // experiments
+    if (wpi_env > 0 && 28 % wpi_env == 0) wpi = wpi_env;
+    static RvitLdsLimit lim_roll;
+    if (const int rc = lim_roll.ensure({(const void*)conv1_pool_roll_kernel}, ROLL_LDS, "stem_conv1_pool")) return rc;
+    hipLaunchKernelGGL(conv1_pool_roll_kernel, dim3((unsigned)(B * wpi)), dim3(512), ROLL_LDS, st, (const float*)img,
+                       (const bf16*)w, scale, bias, (bf16*)pooled, wpi);
+    RVIT_CHECK_LAUNCH("stem_conv1_pool");
+    return RVIT_OK;
+  }
   static RvitLdsLimit lim;
   if (const int rc = lim.ensure({(const void*)conv1_pool_kernel<false>, (const void*)conv1_pool_kernel<true>}, CO_BYTES,
                                 "stem_conv1_pool"))
