@@ -317,7 +317,7 @@ def vitl_infer(args, dev, dist, world, rank, batch=None, steps=None, warmup=None
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-e4m3 (MX)",
            "data": "synthetic",
            "config": {"workload": "ViT-L/16-scale radar ViT (patch16, E1024/H16/L24, 11 classes) batched inference, "
-                                  "MX-fp8 encoder Linears (weights + activations), fp8-MFMA attention with MX-fp8 output, fp32 LayerNorm statistics",
+                                  "MX-fp8 encoder Linears (weights + activations), " + ("fp8-MFMA attention" if os.environ.get("RVIT_FP8_ATTENTION") == "1" else "bf16-MFMA attention") + " with MX-fp8 output, fp32 LayerNorm statistics",
                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-shard x{world}"},
            "model_tflops": round(value * VITL_FWD_FLOPS_PER_SAMPLE / 1e12, 2),
            "mfma_util_model": round(value * VITL_FWD_FLOPS_PER_SAMPLE / 1e12 / (FP8_MFMA_PEAK_TFLOPS * world), 4),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 21
+#define RVIT_ABI_VERSION 22
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -390,6 +390,14 @@ int rvit_attn_fwd_s64(const void* qkv, void* out, int B, int S, int H, int64_t l
  *   (H even: K % 128 == 0).  The reference has no fp8 path; oracle/ref_mxfp8.py restates this arithmetic. */
 int rvit_attn_fwd_fp8(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out_s, int B, int S, int H, int64_t ldq,
                       float scale, void* stream);
+
+/* The MX-fp8 inference mode's default attention since round 3: rvit_attn_fwd (bf16 MFMA, torch functional.py:6623-6631)
+ * with the output row rounded to bf16 and written as the MXFP8 operand of the out_proj GEMM: the same bytes as
+ * rvit_attn_fwd followed by rvit_quantize_mxfp8, without the bf16 attention map and the quantisation pass.  (Un-scaled
+ * fp8 MFMAs run at the bf16 rate on gfx950 and rvit_attn_fwd_fp8 pays for quantising q/k/v/p on the vector ALUs: 185
+ * against 140 us per ViT-L layer at B = 256.)  Arguments as rvit_attn_fwd_fp8. */
+int rvit_attn_fwd_mx(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out_s, int B, int S, int H, int64_t ldq,
+                     float scale, void* stream);
 
 /* Backward of rvit_attn_fwd: dqkv (same layout as qkv) from qkv, out, dout and the saved lse;
  * (drop_p, drop_seed) must be the forward's. */

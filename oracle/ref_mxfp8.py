@@ -83,7 +83,7 @@ def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Te
 
 @torch.no_grad()
 def encoder_layer_mxfp8(L, t: torch.Tensor, quantize: bool = True, bf16_points: bool = False,
-                        fp8_attention: bool = True) -> torch.Tensor:
+                        fp8_attention: bool = False) -> torch.Tensor:
     """One pre-LN encoder layer on the fp32 token stream t [B,S,E] with MXFP8 Linears and (quantize and
     fp8_attention) the fp8 attention above.  bf16_points rounds the tensors the HIP path stores in bf16 before it
     quantises them (LayerNorm output, qkv, attention output)."""
@@ -107,8 +107,10 @@ def encoder_layer_mxfp8(L, t: torch.Tensor, quantize: bool = True, bf16_points: 
 
 @torch.no_grad()
 def forward_mxfp8_emulated(ref: CNNViTHybridRef, x: torch.Tensor, quantize: bool = True,
-                           features_only: bool = False, taps: list = None) -> torch.Tensor:
-    """taps (optional list) receives the fp32 token stream before the first layer and after every layer."""
+                           features_only: bool = False, taps: list = None, fp8_attention: bool = False) -> torch.Tensor:
+    """taps (optional list) receives the fp32 token stream before the first layer and after every layer.
+    fp8_attention: the attention products from e4m3 operands too (the HIP path's fp8_attention option); default, as
+    the HIP path's default since round 3: fp32 softmax attention whose output is MX-quantised for the out_proj."""
     fq = mx_fake_quant if quantize else (lambda t: t)
     B = x.shape[0]
     t = x
@@ -119,7 +121,7 @@ def forward_mxfp8_emulated(ref: CNNViTHybridRef, x: torch.Tensor, quantize: bool
     if taps is not None:
         taps.append(t.clone())
     for L in ref.transformer.layers:
-        t = encoder_layer_mxfp8(L, t, quantize)
+        t = encoder_layer_mxfp8(L, t, quantize, fp8_attention=fp8_attention)
         if taps is not None:
             taps.append(t.clone())
     c = ref.norm(t[:, 0])

@@ -561,3 +561,29 @@ def test_stem_conv1_pool_fused(dev, B):
     p3 = torch.full_like(pooled, float("nan"))
     ops.stem_conv1_pool_f32(x.to(dev), w232.to(dev), scale.to(dev), bias.to(dev), p3)
     assert torch.equal(p3, pooled)
+
+
+@pytest.mark.parametrize("B", [37, 74, 130, 260, 512])
+def test_stem_conv1_pool_rolling_band_splits(dev, B):
+    """The rolling-band stem entry (fp32 input; what inference runs) picks 14 / 7 / 4 / 2 / 1 workgroups per image at
+    these batch sizes on a 256-CU device (28 / wpi bands each, the first one computing the carried conv row on its own):
+    every split must give the band kernel's bits on the packed input, including a negative folded-BN scale."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(700 + B)
+    x = torch.randn(B, 3, 224, 224, generator=g).to(dev)
+    w = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    wp = torch.zeros(64, 7, 8, 4)
+    wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    w232 = torch.zeros(64, 232, dtype=torch.bfloat16)
+    w232[:, :224] = _bf(wp).reshape(64, 224)
+    w232 = w232.to(dev)
+    scale = torch.rand(64, generator=g) + 0.5
+    scale[5] = -0.7
+    scale, bias = scale.to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+    xp = torch.zeros(B, 230, 232, 4, dtype=torch.bfloat16, device=dev)
+    ops.input_pack(x, xp, 3, 3)
+    ref = torch.empty(B, 56, 56, 64, dtype=torch.bfloat16, device=dev)
+    ops.stem_conv1_pool(xp, w232, scale, bias, ref)
+    out = torch.full_like(ref, float("nan"))
+    ops.stem_conv1_pool_f32(x, w232, scale, bias, out)
+    assert torch.equal(out, ref)

@@ -170,6 +170,10 @@ MODEL_CASES = [
 
 
 # measured (|hip - emulation|, |hip - fp32|): 0.583 / 1.093, 0.767 / 0.806, 0.371 / 0.653, 0.400 / 0.788
+# the default mode (bf16-MFMA attention with MX output), measured 1.220 / 0.668, 0.678 / 0.663, 0.575 / 0.693, 0.401 / 0.902
+MX_MODEL_BOUND_BF16_ATTN = {"vit-E256-L4": (1.83, 1.00), "R-hybrid": (1.02, 1.00), "vit-E768-L3": (0.86, 1.04),
+                            "vit-L-scale-E1024-H16-L2": (0.60, 1.35)}
+# fp8_attention=True (both attention products on the fp8 MFMA):
 MX_MODEL_BOUND = {"vit-E256-L4": (0.88, 1.64), "R-hybrid": (1.15, 1.21), "vit-E768-L3": (0.56, 0.98),
                   "vit-L-scale-E1024-H16-L2": (0.60, 1.19)}
 
@@ -186,8 +190,9 @@ def _mx_pair(cfg, dev):
     return m.to(dev).eval(), ref.eval()
 
 
+@pytest.mark.parametrize("fp8_attn", [False, True], ids=["attn-bf16", "attn-fp8"])
 @pytest.mark.parametrize("name,cfg,B", MODEL_CASES, ids=[c[0] for c in MODEL_CASES])
-def test_encoder_layers_mxfp8_teacher_forced(dev, name, cfg, B):
+def test_encoder_layers_mxfp8_teacher_forced(dev, name, cfg, B, fp8_attn):
     """Every encoder layer in mxfp8 mode, fed the emulation's fp32 token stream, against the emulation of that
     one layer (oracle/ref_mxfp8.py, with the HIP path's bf16 storage points).  The kernels themselves are
     exact (tests above: bit-exact quantiser, GEMM equal to the dequantised matmul); but the two sides quantise
@@ -200,24 +205,25 @@ def test_encoder_layers_mxfp8_teacher_forced(dev, name, cfg, B):
     from vit_amd.synth import micro_doppler_batch
     torch.set_num_threads(16)
     m, ref = _mx_pair(cfg, dev)
-    m.set_inference_precision("mxfp8")
+    m.set_inference_precision("mxfp8", fp8_attention=fp8_attn)
     x = micro_doppler_batch(B, seed=31)
     taps = []
-    forward_mxfp8_emulated(ref, x, taps=taps)
+    forward_mxfp8_emulated(ref, x, taps=taps, fp8_attention=fp8_attn)
     eng = m.engine
     P, b = eng.pack(), eng.buffers(B, dev)
     with torch.no_grad():
         for i, (L, Lref) in enumerate(zip(P["layers"], ref.transformer.layers)):
             b["x"].copy_(taps[i].to(dev))
             eng._encoder_layer(L, b, B)
-            want = encoder_layer_mxfp8(Lref, taps[i], bf16_points=True)
+            want = encoder_layer_mxfp8(Lref, taps[i], bf16_points=True, fp8_attention=fp8_attn)
             d = (b["x"].cpu() - want).abs()
             print(f"[{name} layer {i}] max {d.max():.4f} mean {d.mean():.5f} (mean |x| {want.abs().mean():.3f})")
             assert d.max().item() <= 0.25 and d.mean().item() <= 0.02
 
 
+@pytest.mark.parametrize("fp8_attn", [False, True], ids=["attn-bf16", "attn-fp8"])
 @pytest.mark.parametrize("name,cfg,B", MODEL_CASES, ids=[c[0] for c in MODEL_CASES])
-def test_model_mxfp8_inference_matches_emulation(dev, name, cfg, B):
+def test_model_mxfp8_inference_matches_emulation(dev, name, cfg, B, fp8_attn):
     """set_inference_precision('mxfp8') end to end against the CPU emulation of the same format.  Per layer the
     two agree closely (test above); over the whole network their rounding decisions decorrelate, so the end-to-end
     difference is of the size of the quantisation noise itself.  Stated tolerance (FIXED per case, 1.5 x the values
@@ -231,20 +237,20 @@ def test_model_mxfp8_inference_matches_emulation(dev, name, cfg, B):
     x = micro_doppler_batch(B, seed=31)
     with torch.no_grad():
         fp32 = ref(x)
-        emu = forward_mxfp8_emulated(ref, x)
+        emu = forward_mxfp8_emulated(ref, x, fp8_attention=fp8_attn)
         bf = m(x.to(dev)).cpu()
-        m.set_inference_precision("mxfp8")
+        m.set_inference_precision("mxfp8", fp8_attention=fp8_attn)
         mx = m(x.to(dev)).cpu()
         mx2 = m(x.to(dev)).cpu()
         m.set_inference_precision("bf16")
         bf2 = m(x.to(dev)).cpu()
     err = (mx - emu).abs()
     cost = (emu - fp32).abs().max().item()
-    print(f"\n[{name}] |hip mxfp8 - emulation| max {err.max():.4f}; format cost |emulation - fp32| max {cost:.4f}; "
+    print(f"\n[{name} fp8_attention={fp8_attn}] |hip mxfp8 - emulation| max {err.max():.4f}; format cost |emulation - fp32| max {cost:.4f}; "
           f"|hip mxfp8 - fp32| max {(mx - fp32).abs().max():.4f}; |hip bf16 - fp32| max {(bf - fp32).abs().max():.4f}")
     assert torch.equal(mx, mx2) and torch.equal(bf, bf2)          # deterministic; switching back restores bf16
     assert not torch.equal(mx, bf)
-    b_emu, b_fp32 = MX_MODEL_BOUND[name]
+    b_emu, b_fp32 = (MX_MODEL_BOUND if fp8_attn else MX_MODEL_BOUND_BF16_ATTN)[name]
     assert err.max().item() <= b_emu, (err.max().item(), b_emu)
     assert (mx - fp32).abs().max().item() <= b_fp32
     srt = fp32.sort(dim=1).values
@@ -316,3 +322,21 @@ def test_attention_fp8_matches_emulation(dev, B, S, H):
     rel = ((got - ref).norm() / ref.norm()).item()
     print(f"   relative L2 against fp32 attention {rel:.4f}")
     assert rel <= 0.11
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 197, 16), (3, 50, 4), (1, 256, 2), (5, 33, 12)])
+def test_attention_mx_equals_attention_then_quantize(dev, B, S, H):
+    """rvit_attn_fwd_mx (the mxfp8 mode's default attention) must write exactly the bytes of rvit_attn_fwd followed by
+    rvit_quantize_mxfp8 on its bf16 output: values and tiled E8M0 scales."""
+    from vit_amd import ops
+    E = H * 64
+    g = torch.Generator().manual_seed(1000 + S)
+    qkv = (torch.randn(B * S, 3 * E, generator=g) * 1.3).to(torch.bfloat16).to(dev)
+    att = torch.empty(B * S, E, dtype=torch.bfloat16, device=dev)
+    ops.attention(qkv, att, B, S, H)
+    q_ref, s_ref = ops.quantize_mx(att)
+    oq = torch.full((B * S, E), 0x7f, dtype=torch.uint8, device=dev)
+    os_ = torch.zeros(ops.mx_scale_shape(B * S, E), dtype=torch.uint8, device=dev)   # as quantize_mx allocates them
+    ops.attention_mx(qkv, oq, os_, B, S, H)
+    assert torch.equal(oq, q_ref)
+    assert torch.equal(os_, s_ref)

@@ -328,6 +328,11 @@ int rvit_attn_fwd_fp8(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out
   return rvit_attn_fwd_fp8_impl(qkv, out_q, ldo, out_s, B, S, H, ldq, scale, (hipStream_t)stream);
 }
 
+int rvit_attn_fwd_mx(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out_s, int B, int S, int H, int64_t ldq,
+                     float scale, void* stream) {
+  return rvit_attn_fwd_mx_impl(qkv, out_q, ldo, out_s, B, S, H, ldq, scale, (hipStream_t)stream);
+}
+
 int rvit_attn_fwd_s64(const void* qkv, void* out, int B, int S, int H, int64_t ldq, int64_t ldo, float scale,
                       void* stream) {
   return rvit_attn16_impl(qkv, out, B, S, H, ldq, ldo, scale, (hipStream_t)stream);

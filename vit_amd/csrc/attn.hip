@@ -83,11 +83,15 @@ __device__ __forceinline__ void attn_store_row(bf16* row, const f32x16 (&acc)[2]
       if (ok) *reinterpret_cast<uint4*>(row + db * 32 + 16 * gp + 8 * h2) = w;   // the swaps run on every lane
     }
 }
-template <int NKB>
+// MXOUT (round 3; entry rvit_attn_fwd_mx, the MX-fp8 inference mode's default attention): the same kernel, but the
+// output row is rounded to bf16 (the storage point of the per-op path) and written as the MXFP8 operand of the
+// out_proj GEMM - e4m3 values in `out` (uint8 [T, ldo]) + one E8M0 scale per 32 columns in `out_s` (tiled, gemm_mx.hip)
+// - exactly the bytes rvit_attn_fwd + rvit_quantize_mx produce, without the bf16 map and the quantisation pass.
+template <int NKB, bool MXOUT = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int total_pairs, int S, int H,
                                                        long ldq, long ldo, float scale_log2e, float scale,
-                                                       DropKey dk) {
+                                                       DropKey dk, uint8_t* __restrict__ out_s = nullptr) {
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int SP = 32 * NKB;
   constexpr int PAIR_BYTES = SP * 256;   // K image, V image (du_off layout)
@@ -222,7 +226,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     }
     if (qi == wave) ATTN_FSTAMP(5);
     const float inv = 1.0f / sum;
-    attn_store_row(out + ((long)b * S + (q_ok ? query : 0)) * ldo + h * 64, o, h2, inv, q_ok);
+    if constexpr (MXOUT) {
+      // a row's 64 columns sit in the lane pair (lane, lane + 32): per 32-column block db the lane holds columns
+      // 8g + 4h2 + (0..3), g = 0..3 (as attn_fwd_fp8_kernel's epilogue)
+      uint8_t* const out_q = reinterpret_cast<uint8_t*>(out);
+      const long token = (long)b * S + query;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        float am = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          o[db][r] = (float)(bf16)(o[db][r] * inv);
+          am = fmaxf(am, fabsf(o[db][r]));
+        }
+        am = fmaxf(am, __shfl_xor(am, 32, 64));
+        const int sE = mx_scale_e8m0(am);
+        const float qinv = mx_inv_scale(sE);
+        if (q_ok) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint32_t*>(out_q + token * ldo + h * 64 + db * 32 + 8 * g + 4 * h2) =
+                mx_pack4(o[db][4 * g + 0], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3], qinv);
+          if (h2 == 0) out_s[mx_scale_offset(token, h * 64 + db * 32, E)] = (uint8_t)sE;
+        }
+      }
+    } else {
+      attn_store_row(out + ((long)b * S + (q_ok ? query : 0)) * ldo + h * 64, o, h2, inv, q_ok);
+    }
     if (q_ok && lse && h2 == 0) lse[(long)pair * S + query] = mx * scale + logf(sum);
     if (qi == wave) ATTN_FSTAMP(6);
   }
@@ -241,6 +271,22 @@ int launch_attn_fwd(const bf16* qkv, bf16* out, float* lse, int B, int S, int H,
   hipLaunchKernelGGL((attn_fwd_kernel<NKB>), dim3(grid), dim3(256), LDS, st, qkv, out, lse, total, S, H, ldq, ldo,
                      scale * 1.44269504088896340736f, scale, dk);
   RVIT_CHECK_LAUNCH("attn_fwd");
+  return RVIT_OK;
+}
+
+template <int NKB>
+int launch_attn_fwd_mx(const bf16* qkv, uint8_t* out_q, uint8_t* out_s, int B, int S, int H, long ldq, long ldo,
+                       float scale, hipStream_t st) {
+  constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
+  constexpr int LDS = PAIRS * 32 * NKB * 256;
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)attn_fwd_kernel<NKB, true>}, LDS, "attn_fwd_mx")) return rc;
+  const int total = B * H;
+  const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
+  hipLaunchKernelGGL((attn_fwd_kernel<NKB, true>), dim3(grid), dim3(256), LDS, st, qkv, reinterpret_cast<bf16*>(out_q),
+                     (float*)nullptr, total, S, H, ldq, ldo, scale * 1.44269504088896340736f, scale, make_drop_key(0.f, 0),
+                     out_s);
+  RVIT_CHECK_LAUNCH("attn_fwd_mx");
   return RVIT_OK;
 }
 
@@ -885,5 +931,29 @@ int rvit_attn_fwd_fp8_impl(const void* qkv, uint8_t* out_q, long ldo, uint8_t* o
     case 8: return launch_attn_fwd_fp8<8>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
   }
   rvit_set_error("attn_fwd_fp8: S=%d unsupported", S);
+  return RVIT_EUNSUPPORTED;
+}
+
+int rvit_attn_fwd_mx_impl(const void* qkv, uint8_t* out_q, long ldo, uint8_t* out_s, int B, int S, int H, long ldq,
+                          float scale, hipStream_t st) {
+  RVIT_CHECK_ARG(qkv && out_q && out_s, "attn_fwd_mx: null pointer");
+  RVIT_CHECK_ARG(B > 0 && H > 0 && S > 0 && S <= 256, "attn_fwd_mx: unsupported shape B=%d H=%d S=%d (S<=256)", B, H, S);
+  RVIT_CHECK_ARG((H & 1) == 0, "attn_fwd_mx: H * 64 must be a multiple of 128 (MX operand of the out_proj), H=%d", H);
+  RVIT_CHECK_ARG(ldq >= 3L * H * 64 && (ldq & 7) == 0 && ldo >= (long)H * 64 && (ldo & 3) == 0,
+                 "attn_fwd_mx: bad pitches ldq=%ld ldo=%ld", ldq, ldo);
+  RVIT_CHECK_ARG(rvit_aligned16(qkv) && ((uintptr_t)out_q & 3) == 0, "attn_fwd_mx: alignment");
+  RVIT_CHECK_ARG((long)B * H < 0x7fffffffL, "attn_fwd_mx: too many (image, head) pairs");
+  const bf16* q = (const bf16*)qkv;
+  switch ((S + 31) / 32) {
+    case 1: return launch_attn_fwd_mx<1>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 2: return launch_attn_fwd_mx<2>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 3: return launch_attn_fwd_mx<3>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 4: return launch_attn_fwd_mx<4>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 5: return launch_attn_fwd_mx<5>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 6: return launch_attn_fwd_mx<6>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 7: return launch_attn_fwd_mx<7>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+    case 8: return launch_attn_fwd_mx<8>(q, out_q, out_s, B, S, H, ldq, ldo, scale, st);
+  }
+  rvit_set_error("attn_fwd_mx: S=%d unsupported", S);
   return RVIT_EUNSUPPORTED;
 }

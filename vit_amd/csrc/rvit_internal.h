@@ -161,6 +161,8 @@ int rvit_attn_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int
                        float drop_p, uint64_t drop_seed, hipStream_t st);
 int rvit_attn_fwd_fp8_impl(const void* qkv, uint8_t* out_q, long ldo, uint8_t* out_s, int B, int S, int H, long ldq,
                            float scale, hipStream_t st);
+int rvit_attn_fwd_mx_impl(const void* qkv, uint8_t* out_q, long ldo, uint8_t* out_s, int B, int S, int H, long ldq,
+                          float scale, hipStream_t st);
 int rvit_dwconv_impl(const void* x, const void* w, const float* scale, const float* bias, void* out, int B, int H, int W,
                      int C, int K, int stride, int pad, int act, hipStream_t st);
 int rvit_avgpool_impl(const void* x, void* out, int B, int HW, int C, hipStream_t st);

@@ -55,13 +55,18 @@ class Engine:
         # (e4m3 + E8M0 per 32) weights and activations; LayerNorm, softmax, the residual stream, the stem, the
         # patch embedding and the head stay bf16 / fp32 (BASELINE.json configs[4])
         self.precision = "bf16"
+        # mxfp8 mode: attention products on the fp8 MFMA too (rvit_attn_fwd_fp8) instead of the bf16-MFMA kernel with an
+        # MX epilogue (rvit_attn_fwd_mx, the default since round 3: faster on gfx950, and closer to the fp32 oracle)
+        self.fp8_attention = os.environ.get("RVIT_FP8_ATTENTION", "0") == "1"
         # fused encoder-layer kernels where the shape allows (RVIT_ENCODER_FUSED=0: the per-op path, for A/B runs)
         self.fused_encoder = os.environ.get("RVIT_ENCODER_FUSED", "1") != "0"
         self.FUSED_MIN_TOKENS = int(os.environ.get("RVIT_FUSED_MIN_TOKENS", "12800"))
         self.fused_stack = os.environ.get("RVIT_ENCODER_STACK", "1") != "0"   # all layers in one launch (A/B: 0 = per layer)
         self.graph_max_batch = 0
 
-    def set_precision(self, precision: str) -> None:
+    def set_precision(self, precision: str, fp8_attention=None) -> None:
+        if fp8_attention is not None:
+            self.fp8_attention = bool(fp8_attention)
         if precision not in ("bf16", "mxfp8"):
             raise ValueError(f"unknown inference precision {precision!r}; choose 'bf16' or 'mxfp8'")
         if precision == "mxfp8" and (self.m.embed_dim % 128 != 0):
@@ -316,8 +321,13 @@ class Engine:
             # LayerNorm emits its result directly as MX-fp8 (same bytes as layernorm -> quantize_mx, one pass)
             ops.layernorm_mx(x2, L["ln1_w"], L["ln1_b"], aq, as_, L["eps1"])
             ops.gemm_mx(aq, as_, L["qkv_w_q"], L["qkv_w_s"], b["qkv"], bias=L["qkv_b"])
-            # both attention products on the fp8 MFMA; the result is written as the MX operand of the out_proj
-            ops.attention_fp8(b["qkv"], aq, as_, B, S, H)
+            # the attention result is written as the MX operand of the out_proj.  Default: the bf16-MFMA kernel with
+            # an MX epilogue (un-scaled fp8 MFMAs run at the bf16 rate on gfx950 and quantising q / k / v / p costs
+            # vector-ALU time: 185 vs 140 us per ViT-L layer); fp8_attention: both products on the fp8 MFMA
+            if self.fp8_attention:
+                ops.attention_fp8(b["qkv"], aq, as_, B, S, H)
+            else:
+                ops.attention_mx(b["qkv"], aq, as_, B, S, H)
             ops.gemm_mx(aq, as_, L["out_w_q"], L["out_w_s"], x2, bias=L["out_b"], residual=x2)
             ops.layernorm_mx(x2, L["ln2_w"], L["ln2_b"], aq, as_, L["eps2"])
             # linear1's epilogue emits the GELU output directly as MX-fp8 (no bf16 copy, no quantisation pass)

@@ -351,9 +351,11 @@ class CNNViTHybrid(nn.Module):
         self.invalidate_packs()
         return super().train(mode)
 
-    def set_inference_precision(self, precision: str) -> None:
-        """'bf16' (default) or 'mxfp8': encoder Linears on the block-scaled fp8 MFMA (eval mode only)."""
-        self.engine.set_precision(precision)
+    def set_inference_precision(self, precision: str, fp8_attention=None) -> None:
+        """'bf16' (default) or 'mxfp8': encoder Linears on the block-scaled fp8 MFMA (eval mode only).
+        fp8_attention (mxfp8 only; default False, env RVIT_FP8_ATTENTION=1): both attention products on the fp8 MFMA
+        as well, instead of the bf16-MFMA attention with an MX-fp8 output epilogue."""
+        self.engine.set_precision(precision, fp8_attention)
 
     def set_graph_capture(self, max_batch: int = 16) -> None:
         """Replay eval-mode forwards of up to `max_batch` frames from a captured HIP graph (0 disables)."""

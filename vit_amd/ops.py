@@ -867,6 +867,25 @@ def attention_fp8(qkv: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, B
     return out_q, out_s
 
 
+def attention_mx(qkv: torch.Tensor, out_q: torch.Tensor, out_s: torch.Tensor, B: int, S: int, H: int,
+                 scale: Optional[float] = None):
+    """attention() on the bf16 MFMA with the output written as MXFP8 (the bytes attention() -> quantize_mx() give):
+    the MX-fp8 inference mode's default.  Arguments as attention_fp8."""
+    _need_cuda(qkv, out_q, out_s)
+    T, W3, ldq = _rows2d(qkv, "attention_mx qkv")
+    E = H * 64
+    if T != B * S or W3 != 3 * E or qkv.dtype != BF16 or E % 128:
+        raise ValueError(f"attention_mx: qkv {tuple(qkv.shape)} does not match B={B} S={S} H={H} (H even)")
+    if tuple(out_q.shape) != (T, E) or out_q.dtype != torch.uint8 or out_q.stride(1) != 1 \
+            or tuple(out_s.shape) != mx_scale_shape(T, E) or out_s.dtype != torch.uint8 or not out_s.is_contiguous():
+        raise ValueError("attention_mx: out_q [T,E] / tiled out_s (ops.mx_scale_shape) must be uint8")
+    sc = (1.0 / 8.0) if scale is None else float(scale)
+    with _Span("attn_fwd", 4 * B * H * S * S * 64, qkv.numel() * 2 + out_q.numel()):
+        check(_lib.load().rvit_attn_fwd_mx(qkv.data_ptr(), out_q.data_ptr(), out_q.stride(0), out_s.data_ptr(), B, S, H,
+                                           ldq, sc, _stream()), "rvit_attn_fwd_mx")
+    return out_q, out_s
+
+
 # =================================================================================================
 # backward / loss kernels
 # =================================================================================================
