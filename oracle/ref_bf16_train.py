@@ -78,3 +78,41 @@ def emulate_hip_training_storage(ref: CNNViTHybridRef) -> None:
                 mod.downsample[0].register_forward_hook(rnd)
                 mod.downsample[1].register_forward_hook(rnd)
             mod.register_forward_hook(rnd)
+
+
+class _ForceValueSTE(torch.autograd.Function):
+    """Forward: the given value; backward: the gradient passes to the module's own output unchanged."""
+    @staticmethod
+    def forward(ctx, own, forced):
+        return forced.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def stem_convs_in_order(ref: CNNViTHybridRef) -> list:
+    """The resnet stem's convolutions in the order vit_amd/trainer.py saves their outputs: conv1, then per block
+    conv1, [downsample conv], conv2."""
+    cb = ref.cnn_backbone
+    out = [("conv1", cb.conv1)]
+    for li in range(1, 5):
+        for bi, blk in enumerate(getattr(cb, f"layer{li}")):
+            out.append((f"layer{li}.{bi}.conv1", blk.conv1))
+            if blk.downsample is not None:
+                out.append((f"layer{li}.{bi}.downsample.0", blk.downsample[0]))
+            out.append((f"layer{li}.{bi}.conv2", blk.conv2))
+    return out
+
+
+def force_stem_conv_outputs(ref: CNNViTHybridRef, forced: dict) -> None:
+    """Teacher forcing for the training-step parity test: every stem convolution of the oracle RETURNS the map the HIP
+    path stored for it (`forced[name]`, NCHW fp32 holding bf16 values) while its gradient still flows through the
+    oracle's own convolution.  With the conv outputs pinned, every BatchNorm statistic, ReLU decision and max-pool
+    argmax of the oracle coincides with the HIP forward's, so the two backward passes can be compared tensor by tensor
+    at the precision of the gradient arithmetic itself (a free-running comparison on a random-weight network is
+    dominated by ReLU decisions that flip between two bf16-rounded forwards: tests/test_train_gpu.py).  Call BEFORE
+    emulate_hip_training_storage so that its bf16 rounding of the incoming gradient applies behind the forced value."""
+    for name, conv in stem_convs_in_order(ref):
+        val = forced[name]
+        conv.register_forward_hook(lambda m, i, o, v=val: _ForceValueSTE.apply(o, v))
