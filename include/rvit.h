@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 22
+#define RVIT_ABI_VERSION 23
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -121,6 +121,21 @@ int rvit_quantize_mxfp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_
 int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cpix, int seg_len, int KH,
                          int KW, int stride, int pad, int Ho, int Wo, int Cout, const float* scale,
                          const float* bias, const void* residual, int act, int tile, void* stream);
+
+/* rvit_conv2d_fwd_bf16 without scale / bias / residual / activation (the conv of a train-mode conv -> BatchNorm pair,
+ * timm resnet in train(): train_vit.py:87,935-937) whose epilogue ALSO produces the BatchNorm batch statistics of the
+ * map it stores (round 3): every M tile writes the per-channel sum and sum of squares of its bf16-ROUNDED outputs to
+ * its own slot, stat_ws[slot * 2 Cout + c] and [slot * 2 Cout + Cout + c] (fp32, a fixed association inside the tile, no
+ * atomics); rvit_bn_stats_finalize then adds the slots in order into `sums` - the values rvit_bn_stats would compute from
+ * the stored map, without the pass over it (104 us for the 411 MB map of the stem's first conv at B = 256).
+ *   *stat_slots receives the number of slots the chosen kernel writes; 0 = this kernel has no statistics epilogue (or the
+ *   slots do not fit stat_ws_bytes): the conv has run as rvit_conv2d_fwd_bf16 would and the caller falls back to
+ *   rvit_bn_stats.  stat_ws 16-byte aligned.
+ *   rvit_bn_stats_finalize: sums[0..2C) += slots; stage: scratch of >= 256 * 2C floats, needed above 512 slots. */
+int rvit_conv2d_fwd_stats_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cpix, int seg_len, int KH,
+                               int KW, int stride, int pad, int Ho, int Wo, int Cout, void* stat_ws, int64_t stat_ws_bytes,
+                               int* stat_slots, int tile, void* stream);
+int rvit_bn_stats_finalize(const void* stat_ws, int stat_slots, int C, float* sums, void* stage, void* stream);
 
 /* Which kernel rvit_conv2d_fwd_bf16 / rvit_conv2d_dgrad_bf16 run (tile 0) for a 3x3 / stride 1 / pad 1 convolution of B
  * images of H x W x Cin -> Cout (16-byte aligned operands): 0 implicit-GEMM gather kernel, 1 generic direct kernel

@@ -587,3 +587,63 @@ def test_stem_conv1_pool_rolling_band_splits(dev, B):
     out = torch.full_like(ref, float("nan"))
     ops.stem_conv1_pool_f32(x, w232, scale, bias, out)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("case", ["conv1-7x7s2", "3x3s2", "1x1s2", "3x3s1-small"])
+def test_conv_epilogue_batch_statistics(dev, case):
+    """rvit_conv2d_fwd_stats_bf16 (round 3): where the conv kernel has the statistics epilogue, the per-tile slots summed
+    by rvit_bn_stats_finalize must equal what rvit_bn_stats computes from the stored map (same bf16 values, another
+    summation order: fp32 round-off), the stored map must be bit-identical to rvit_conv2d_fwd_bf16's, and two runs must
+    give identical sums (no atomics)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(91)
+    if case == "conv1-7x7s2":
+        B = 20
+        x = torch.zeros(B, 230, 232, 4, dtype=torch.bfloat16)
+        x[:, 3:227, 3:227, :3] = torch.randn(B, 224, 224, 3, generator=g).to(torch.bfloat16)
+        w = _bf(torch.randn(64, 7 * 32, generator=g) / 12)
+        kw = dict(kh=7, kw=1, stride=2, pad=0, seg_len=32)
+        out_shape = (B, 112, 112, 64)   # 980 M tiles of 256 rows: the two-stage finalisation
+    elif case == "3x3s2":
+        B = 6
+        x = torch.randn(B, 56, 56, 64, generator=g).to(torch.bfloat16)
+        w = _bf(torch.randn(128, 9 * 64, generator=g) / 24)
+        kw = dict(kh=3, kw=3, stride=2, pad=1)
+        out_shape = (B, 28, 28, 128)
+    elif case == "1x1s2":
+        B = 5
+        x = torch.randn(B, 28, 28, 128, generator=g).to(torch.bfloat16)
+        w = _bf(torch.randn(256, 128, generator=g) / 11)
+        kw = dict(kh=1, kw=1, stride=2, pad=0)
+        out_shape = (B, 14, 14, 256)
+    else:
+        B = 3
+        x = torch.randn(B, 14, 14, 256, generator=g).to(torch.bfloat16)
+        w = _bf(torch.randn(256, 9 * 256, generator=g) / 48)
+        kw = dict(kh=3, kw=3, stride=1, pad=1)
+        out_shape = (B, 14, 14, 256)
+    x, w = x.to(dev), w.to(dev)
+    C = out_shape[-1]
+    y_ref = torch.empty(out_shape, dtype=torch.bfloat16, device=dev)
+    ops.conv2d(x, w, y_ref, **kw)
+    want = torch.zeros(2 * C, device=dev)
+    ops.bn_stats(y_ref, want, ops.bn_workspace(dev))
+    ws = ops.conv_stats_workspace(dev)
+    runs = []
+    fused = None
+    for _ in range(2):
+        y = torch.full(out_shape, float("nan"), dtype=torch.bfloat16, device=dev)
+        sums = torch.zeros(2 * C, device=dev)
+        fused = ops.conv2d_bn_stats(x, w, y, sums, ws, bn_workspace=ops.bn_workspace(dev), **kw)
+        assert torch.equal(y, y_ref)
+        runs.append(sums)
+    assert torch.equal(runs[0], runs[1])
+    yf = y_ref.float().reshape(-1, C)
+    exact = torch.cat([yf.double().sum(0), (yf.double() ** 2).sum(0)]).float()
+    scale = torch.cat([yf.abs().double().sum(0), (yf.double() ** 2).sum(0)]).float().clamp_min(1e-6)
+    err = ((runs[0] - exact).abs() / scale).max().item()
+    err_ref = ((want - exact).abs() / scale).max().item()
+    print(f"\n[{case}] fused epilogue: {fused}; |sums - exact| / sum|y|: epilogue {err:.2e}, bn_stats {err_ref:.2e}")
+    assert err <= 2e-5
+    if case != "3x3s1-small":
+        assert fused, "the implicit-GEMM kernel has the statistics epilogue"

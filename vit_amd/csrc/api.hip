@@ -113,6 +113,32 @@ int rvit_conv2d_fwd_bf16(const void* x, const void* w, void* y, int B, int H, in
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_conv2d_fwd_stats_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cpix, int seg_len, int KH,
+                               int KW, int stride, int pad, int Ho, int Wo, int Cout, void* stat_ws, int64_t stat_ws_bytes,
+                               int* stat_slots, int tile, void* stream) {
+  RVIT_CHECK_ARG(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+                 "conv: bad geometry");
+  RVIT_CHECK_ARG((long)B * H * W < 0x7fffffffL, "conv: B*H*W exceeds 2^31 pixels");
+  RVIT_CHECK_ARG((Ho - 1) * stride - pad + KH - 1 < H + pad + stride && (Wo - 1) * stride - pad < W,
+                 "conv: output size inconsistent with input");
+  RVIT_CHECK_ARG(stat_ws && stat_slots && aligned_to(stat_ws, 16) && stat_ws_bytes >= 0, "conv (stats): workspace / slot count missing");
+  GemmArgs a{};
+  conv_geometry(a, x, w, B, H, W, Cpix, seg_len, KH, KW, stride, pad, Ho, Wo, Cout);
+  a.C = y; a.ldc = Cout; a.c_f32 = 0;
+  a.ldr = Cout;
+  a.tile = tile;
+  a.vec = (Cout & 7) == 0 && aligned_to(y, 16);
+  a.stat_part = (float*)stat_ws;
+  a.stat_cap_slots = (long)(stat_ws_bytes / 4 / (2L * Cout));
+  a.stat_slots = stat_slots;
+  *stat_slots = 0;
+  return rvit_gemm_dispatch(a, (hipStream_t)stream);
+}
+
+int rvit_bn_stats_finalize(const void* stat_ws, int stat_slots, int C, float* sums, void* stage, void* stream) {
+  return rvit_bn_stats_finalize_impl((const float*)stat_ws, stat_slots, C, sums, (float*)stage, (hipStream_t)stream);
+}
+
 int rvit_conv3x3_kernel(int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (long)B * H * W >= 0x7fffffffL) return RVIT_CONV_GATHER;
   GemmArgs a{};

@@ -247,6 +247,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
   char* ep = smem + wave * (EP_ROWS * EP_PITCH);
   const int er = lane >> 3, ec = (lane & 7) * 8;
   const int n = bn0 + wn * WN + ec;
+  float st1[8], st2[8];   // statistics hook (p.stat_part): this lane's 8 columns over the rows it stores
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
 #pragma unroll
   for (int i0 = 0; i0 < MR; i0 += EP_ROWS / 16) {
     if (i0 > 0) __syncthreads();
@@ -267,7 +270,43 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
         const float4 hi = *reinterpret_cast<const float4*>(ep + row * EP_PITCH + ec * 4 + 16);
         v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
       }
-      rvit_gemm_epilogue_row8(p, v, m, n);
+      rvit_gemm_epilogue_row8(p, v, m, n);   // leaves the final fp32 values in v
+      if (p.stat_part) {
+        uint4 o;   // as stored
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        rvit_stat_acc8(o, st1, st2);
+      }
+    }
+  }
+  // ---- per-tile batch statistics (train-mode BatchNorm after a conv): lanes that share a column chunk combine by the
+  // xor butterfly, the waves of a column block through LDS in wave order, one slot per M tile: fixed association,
+  // no atomics (rvit_bn_stats_finalize adds the slots in order)
+  if (p.stat_part) {
+    // lanes l, l ^ 8, l ^ 16, l ^ 32 on the vector ALU (row rotate, lane-row swaps): __shfl_xor would be 48 LDS
+    // crossbar round trips per tile
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      st1[e] = rvit_sum_lanes_8_16_32(st1[e]);
+      st2[e] = rvit_sum_lanes_8_16_32(st2[e]);
+    }
+    __syncthreads();   // every wave has read back its staging rows
+    float* sred = reinterpret_cast<float*>(smem);   // [wave][sum 64 | sumsq 64]
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sred[wave * 128 + lane * 8 + e] = st1[e];
+        sred[wave * 128 + 64 + lane * 8 + e] = st2[e];
+      }
+    }
+    __syncthreads();
+    for (int idx = t; idx < WAVES_N * 128; idx += WAVES_M * WAVES_N * 64) {
+      const int wn_ = idx >> 7, q = idx & 127;
+      float tot = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WAVES_M; ++w_) tot += sred[(w_ * WAVES_N + wn_) * 128 + q];
+      const int col = bn0 + wn_ * WN + (q & 63);
+      if (col < p.N) p.stat_part[(long)tile_m * 2 * p.N + (q >> 6) * p.N + col] = tot;
     }
   }
 }
@@ -285,10 +324,16 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   if (const int rc = lim.ensure({(const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, true>,
                                  (const void*)gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, false>}, lds, "gemm"))
     return rc;
+  GemmArgs b = a;
+  if (b.stat_part) {   // one statistics slot per M tile (this kernel's epilogue writes them)
+    const long slots = (a.M + BM - 1) / BM;
+    if (a.vec && !a.c_f32 && a.row_group == 0 && slots <= a.stat_cap_slots && a.stat_slots) *a.stat_slots = (int)slots;
+    else b.stat_part = nullptr;
+  }
   if (a.mode == 1)
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, true>), dim3((unsigned)tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, true>), dim3((unsigned)tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, b);
   else
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, false>), dim3((unsigned)tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WAVES_M, WAVES_N, STAGES, false>), dim3((unsigned)tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, b);
   RVIT_CHECK_LAUNCH("gemm_bf16");
   return RVIT_OK;
 }
@@ -319,6 +364,7 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   if (a.gate) {
     RVIT_CHECK_ARG(a.G && a.ldg >= a.N, "gemm: gate operand missing");
   }
+  if (a.stat_slots) *a.stat_slots = 0;   // set by the kernels that implement the statistics epilogue
   if (a.M == 0) return RVIT_OK;
   // 3x3 / stride 1 / pad 1 convs (and their input gradients): LDS-resident patch kernel (conv3x3.hip),
   // at every batch size: the kernel choice must not depend on M or a sample's logits would depend on

@@ -213,3 +213,21 @@ __device__ __forceinline__ void rvit_epi_row_apply(const GemmArgs& p, float (&v)
     *reinterpret_cast<uint4*>((bf16*)p.C + orow * p.ldc + n) = o;
   }
 }
+
+// Batch-statistics hook shared by the conv epilogues: sum and sum of squares of eight stored bf16 values
+__device__ __forceinline__ void rvit_stat_acc8(const uint4& o, float (&s1)[8], float (&s2)[8]) {
+  const float x[8] = {bf16_lo(o.x), bf16_hi(o.x), bf16_lo(o.y), bf16_hi(o.y), bf16_lo(o.z), bf16_hi(o.z), bf16_lo(o.w), bf16_hi(o.w)};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] += x[e]; s2[e] = fmaf(x[e], x[e], s2[e]); }
+}
+
+// x summed over the eight lanes l ^ {0, 8, 16, 24, 32, 40, 48, 56} (every lane gets the total; fixed association):
+// DPP row_ror:8 inside the 16-lane row, v_permlane16_swap between rows 0 <-> 1 and 2 <-> 3, v_permlane32_swap between
+// the wave halves.
+__device__ __forceinline__ float rvit_sum_lanes_8_16_32(float x) {
+  x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}

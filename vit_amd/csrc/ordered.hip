@@ -70,7 +70,44 @@ __global__ __launch_bounds__(256) void ordered_finalize_wide_kernel(const float*
   if (ok && g == 0) out[r * ld + c] += t;
 }
 
+// First stage for very many slots (the per-tile statistics of the stem's first conv: 12,544 slots of 128 columns at
+// B = 256): workgroup g adds the slots [g * per, (g + 1) * per) in slot order (eight loads in flight) and stores one
+// slot of a G times smaller array; the second stage is the kernel above.  A fixed association on every run.
+__global__ __launch_bounds__(128) void slot_group_sum_kernel(const float* __restrict__ part, int nslots, int cols, int per,
+                                                             float* __restrict__ out) {
+  const int c = blockIdx.y * 128 + threadIdx.x;
+  if (c >= cols) return;
+  int s = blockIdx.x * per;
+  const int end = s + per < nslots ? s + per : nslots;
+  float t = 0.f;
+  for (; s + 8 <= end; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(part + (long)(s + j) * cols + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += v[j];
+  }
+  for (; s < end; ++s) t += __builtin_nontemporal_load(part + (long)s * cols + c);
+  out[(long)blockIdx.x * cols + c] = t;
+}
+
 }  // namespace
+
+// sums[0..2C) += the per-tile statistics slots a conv epilogue wrote (GemmArgs::stat_part), added in slot order.
+// stage: scratch for the first stage when nslots > 512 (>= 256 * 2C floats), may be null otherwise.
+int rvit_bn_stats_finalize_impl(const float* part, int nslots, int C, float* sums, float* stage, hipStream_t st) {
+  RVIT_CHECK_ARG(part && sums && nslots > 0 && C > 0, "bn_stats_finalize: bad arguments");
+  const int cols = 2 * C;
+  if (nslots > 512) {
+    RVIT_CHECK_ARG(stage != nullptr, "bn_stats_finalize: %d slots need the staging buffer", nslots);
+    const int G = 256, per = (nslots + G - 1) / G, groups = (nslots + per - 1) / per;
+    hipLaunchKernelGGL(slot_group_sum_kernel, dim3((unsigned)groups, (unsigned)((cols + 127) / 128)), dim3(128), 0, st, part,
+                       nslots, cols, per, stage);
+    RVIT_CHECK_LAUNCH("bn_stats_finalize");
+    return rvit_ordered_finalize(stage, groups, cols, sums, 1, cols, cols, st);
+  }
+  return rvit_ordered_finalize(part, nslots, cols, sums, 1, cols, cols, st);
+}
 
 int rvit_ordered_finalize(const float* part, int nslots, long slot_stride, float* out, long rows, int cols, long ld,
                           hipStream_t st) {

@@ -39,6 +39,14 @@ struct GemmArgs {
   int tile;          // 0 = auto, else forced tile config (tests)
   int drop_mode;     // 0 none, RVIT_DROP_PRE_RESIDUAL, RVIT_DROP_POST_ACT; element index = out_row * N + col
   DropKey drop;
+  // Optional batch statistics of the STORED (bf16-rounded) output, for the train-mode BatchNorm that follows a conv
+  // (rvit_conv2d_fwd_stats_bf16): every M tile writes sum and sum of squares of its rows per column to its own slot,
+  // stat_part[slot * 2N + n] / [slot * 2N + N + n]; rvit_bn_stats_finalize adds the slots in order.  Host side: the
+  // dispatcher stores the slot count the chosen kernel will write to *stat_slots (0: the kernel has no such epilogue or
+  // the slots exceed stat_cap_slots - the caller then runs rvit_bn_stats) and clears stat_part in that case.
+  float* stat_part;
+  long stat_cap_slots;
+  int* stat_slots;
 };
 
 int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream);
@@ -135,6 +143,7 @@ struct WgradArgs {
 
 int rvit_ordered_finalize(const float* part, int nslots, long slot_stride, float* out, long rows, int cols, long ld,
                           hipStream_t st);
+int rvit_bn_stats_finalize_impl(const float* part, int nslots, int C, float* sums, float* stage, hipStream_t st);
 int rvit_ordered_splits(long units, long splits, int sub, long elems, size_t ws_bytes, const char* what, long* out);
 
 int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st);

@@ -6,6 +6,7 @@ module has a non-HIP implementation.
 """
 from __future__ import annotations
 
+import ctypes
 import functools
 
 from typing import Optional, Tuple
@@ -304,6 +305,54 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, kh: int, kw: 
                                        pad, Ho, Wo, Cout, _ptr(scale), _ptr(bias), _ptr(residual), _ACT[act], tile,
                                        _stream()), "rvit_conv2d_fwd_bf16")
     return out
+
+
+STAT_STAGE_FLOATS = 256 * 2 * 2048   # first-stage scratch of rvit_bn_stats_finalize (C <= 2048)
+
+
+def conv_stats_workspace(device, mbytes: int = 32) -> torch.Tensor:
+    """Workspace of conv2d_bn_stats: per-tile statistics slots followed by the finalisation's staging area."""
+    return torch.empty(mbytes * (1 << 18) + STAT_STAGE_FLOATS, dtype=torch.float32, device=device)
+
+
+def conv2d_bn_stats(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, sums: torch.Tensor, stat_ws: torch.Tensor, *,
+                    kh: int, kw: int, stride: int, pad: int, seg_len: Optional[int] = None,
+                    bn_workspace: Optional[torch.Tensor] = None, tile: int = 0) -> bool:
+    """conv2d (no scale / bias / residual / activation) + bn_stats of its output: sums[0:C] += sum out, sums[C:2C] +=
+    sum out^2.  Where the conv kernel has the statistics epilogue (rvit_conv2d_fwd_stats_bf16) the sums come from
+    per-tile slots written by the conv itself and the pass over the stored map disappears; otherwise bn_stats runs.
+    Returns True in the first case."""
+    _need_cuda(x, w, out, sums, stat_ws, bn_workspace)
+    if x.dim() != 4 or out.dim() != 4 or not x.is_contiguous() or not out.is_contiguous() or not w.is_contiguous():
+        raise ValueError("conv2d_bn_stats: x/out must be contiguous NHWC 4-D tensors, w contiguous")
+    if x.dtype != BF16 or w.dtype != BF16 or out.dtype != BF16:
+        raise TypeError("conv2d_bn_stats: bf16 only")
+    B, H, W, Cpix = x.shape
+    Bo, Ho, Wo, Cout = out.shape
+    seg = Cpix if seg_len is None else seg_len
+    if Bo != B or w.shape != (Cout, kh * kw * seg):
+        raise ValueError(f"conv2d_bn_stats: weight shape {tuple(w.shape)} != {(Cout, kh * kw * seg)} or batch mismatch")
+    _vec_f32(sums, 2 * Cout, "conv2d_bn_stats: sums")
+    if stat_ws.dtype != torch.float32 or not stat_ws.is_contiguous() or stat_ws.numel() <= STAT_STAGE_FLOATS:
+        raise ValueError("conv2d_bn_stats: stat_ws must come from ops.conv_stats_workspace()")
+    lib = _lib.load()
+    true_k = kh * kw * seg if seg_len is None else kh * (kw * seg - seg // 8 - (seg - seg // 8) // 4)
+    name = "conv2d_gather"
+    if kh == 3 and kw == 3 and stride == 1 and pad == 1 and seg_len is None and tile == 0:
+        name = _conv3x3_name(B, H, W, Cpix, Cout)
+    slots = ctypes.c_int(0)
+    slot_floats = stat_ws.numel() - STAT_STAGE_FLOATS
+    with _Span(name, 2 * B * Ho * Wo * Cout * true_k, _nbytes(x, w, out)):
+        check(lib.rvit_conv2d_fwd_stats_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), B, H, W, Cpix, seg, kh, kw, stride,
+                                             pad, Ho, Wo, Cout, stat_ws.data_ptr(), slot_floats * 4, ctypes.byref(slots),
+                                             tile, _stream()), "rvit_conv2d_fwd_stats_bf16")
+    if slots.value > 0:
+        with _Span("bn_stats_finalize", 0, slots.value * 2 * Cout * 4):
+            check(lib.rvit_bn_stats_finalize(stat_ws.data_ptr(), slots.value, Cout, sums.data_ptr(),
+                                             stat_ws.data_ptr() + slot_floats * 4, _stream()), "rvit_bn_stats_finalize")
+        return True
+    bn_stats(out, sums, bn_workspace)
+    return False
 
 
 def conv2d_tokens(x: torch.Tensor, w: torch.Tensor, tokens: torch.Tensor, pos_embed: torch.Tensor, *, kh: int,

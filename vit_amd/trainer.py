@@ -415,10 +415,19 @@ class TrainEngine:
             self.__dict__["_bn_mods"] = mods
         return [mod.num_batches_tracked for mod in mods]   # looked up per step: .to() replaces the buffers
 
+    def _stat_ws(self, dev):
+        ws = self.__dict__.get("_stat_ws_buf")
+        if ws is None or ws.device != dev:
+            ws = ops.conv_stats_workspace(dev)
+            self.__dict__["_stat_ws_buf"] = ws
+        return ws
+
     def _conv_bn(self, x, w, y, z, bn, fs, *, kh, stride, pad, relu, residual=None, seg_len=None, kw=None, mask=None,
                  ws=None):
-        ops.conv2d(x, w, y, kh=kh, kw=kh if kw is None else kw, stride=stride, pad=pad, seg_len=seg_len)
-        ops.bn_stats(y, fs, ws)
+        # conv + batch statistics: where the conv kernel has the statistics epilogue the sums come from per-tile slots it
+        # writes itself (no pass over the stored map), else rvit_bn_stats runs (csrc/gemm.hip, include/rvit.h)
+        ops.conv2d_bn_stats(x, w, y, fs, self._stat_ws(y.device), kh=kh, kw=kh if kw is None else kw, stride=stride,
+                            pad=pad, seg_len=seg_len, bn_workspace=ws)
         ops.bn_apply(y, fs, bn.weight.detach(), bn.bias.detach(), z, eps=bn.eps, relu=relu, residual=residual,
                      momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, relu_mask=mask)
 
@@ -430,8 +439,8 @@ class TrainEngine:
         ws = b["bn_ws"] if self.ordered_bn else None
         # stem entry: conv 7x7/2, then BatchNorm + ReLU + max-pool in one pass (the normalised 112x112 map is not
         # written: the backward pass needs only its sign bits and the argmax taps)
-        ops.conv2d(b["img"], P["conv1_w"], b["c1_y"], kh=7, kw=1, stride=2, pad=0, seg_len=32)
-        ops.bn_stats(b["c1_y"], fs[off:off + 128], ws)
+        ops.conv2d_bn_stats(b["img"], P["conv1_w"], b["c1_y"], fs[off:off + 128], self._stat_ws(b["c1_y"].device), kh=7,
+                            kw=1, stride=2, pad=0, seg_len=32, bn_workspace=ws)
         ops.bn_apply_pool(b["c1_y"], fs[off:off + 128], cb.bn1.weight.detach(), cb.bn1.bias.detach(), b["pool"],
                           b["pool_arg"], b["c1_m"], eps=cb.bn1.eps, momentum=cb.bn1.momentum,
                           running_mean=cb.bn1.running_mean, running_var=cb.bn1.running_var)
