@@ -109,30 +109,38 @@ def _drop(drop):
     return _DROP_POS[pos], float(p), int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
-# Ordered (bit-reproducible) reductions: one scratch workspace per device, handed to every entry point that would
-# otherwise end a split reduction in fp32 atomics (include/rvit.h "Ordered reductions").  The training engine enables
-# it; calls that share the workspace must be ordered on one stream (they are: the engine's compute stream).
+# Ordered (bit-reproducible) reductions: a scratch workspace handed to every entry point that would otherwise end a
+# split reduction in fp32 atomics (include/rvit.h "Ordered reductions").  One workspace per (device, STREAM): the
+# producers of a launch write their slots and the next launch on the same stream reads them, so calls that share a
+# workspace must be ordered on one stream - keying it by the current stream makes that true by construction (two
+# engines, or direct ops callers, on different streams of one GPU no longer share slots: ADVICE r2), and switching it
+# off only affects the caller's own stream.
 ORDERED_WORKSPACE_BYTES = 192 << 20
 _ORDERED_WS: dict = {}
 
 
-def enable_ordered_reductions(device, enable: bool = True, nbytes: int = ORDERED_WORKSPACE_BYTES) -> None:
+def _ows_key(device) -> tuple:
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        return (idx, _stream())
+
+
+def enable_ordered_reductions(device, enable: bool = True, nbytes: int = ORDERED_WORKSPACE_BYTES) -> None:
+    key = _ows_key(device)
     if not enable:
-        _ORDERED_WS.pop(idx, None)
-    elif idx not in _ORDERED_WS or _ORDERED_WS[idx].numel() < nbytes:
-        _ORDERED_WS[idx] = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+        _ORDERED_WS.pop(key, None)
+    elif key not in _ORDERED_WS or _ORDERED_WS[key].numel() < nbytes:
+        _ORDERED_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", key[0]))
 
 
 def ordered_reductions_enabled(device) -> bool:
-    dev = torch.device(device)
-    return (dev.index if dev.index is not None else torch.cuda.current_device()) in _ORDERED_WS
+    return _ows_key(device) in _ORDERED_WS
 
 
 def _ows(t: torch.Tensor):
-    """(pointer, bytes) of the ordered-reduction workspace of t's device, or (None, 0)."""
-    w = _ORDERED_WS.get(t.device.index)
+    """(pointer, bytes) of the ordered-reduction workspace of t's device and the current stream, or (None, 0)."""
+    w = _ORDERED_WS.get((t.device.index, _stream()))
     return (w.data_ptr(), w.numel()) if w is not None else (None, 0)
 
 
