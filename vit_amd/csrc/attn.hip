@@ -677,6 +677,294 @@ __device__ __forceinline__ void bwd_sweep_keys(const char* sK, const char* sV, c
   }
 }
 
+// ---- pass A with the operands still arriving (round 3, NKB >= 5: S > 128) -------------------------------------------
+// The kernel below staged all four images (126 KB at S = 197) behind ONE barrier: 19k of the 42k cycles a workgroup
+// lives (stamps, profiles/r02_gemm8p_notes.txt section 8), with nothing to hide them behind - the workgroup owns its CU.
+// attn_bwd_pipe_kernel requests everything by LDS-DMA up front, in the order it is needed - K | V, then Q | dO block
+// by block - one 1 KB piece per wave per block (waves 0-3 the first tensor of the pair, waves 4-7 the second), and pass
+// A starts on query block 0 as soon as K, V and that block have landed: before every query block one counted
+// s_waitcnt vmcnt (this wave's piece of the block) and one workgroup barrier (everybody's), the later blocks stay in
+// flight behind the sweep.  delta / lse of all rows are computed first from the global dO and O rows (their loads are
+// the oldest, so consuming them leaves every DMA in flight; dO is read twice, the second time from L2).
+// The transposing reads of the sweep are inline assembly: a ds_read_tr the compiler can see makes its wait-count pass
+// wait for EVERY LDS-DMA in flight (wgrad.hip tr_read_asm) - here that would be the blocks still arriving.
+__device__ __forceinline__ void attn_tr_read_asm(s16x4& dst, uint32_t lds_addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void attn_tr_wait8(s16x4 (&r)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+               :
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void attn_wait_vmcnt_rt(int n) {   // n in [0, 8], wave-uniform
+  switch (n) {
+    case 0: attn_wait_vmcnt<0>(); break;
+    case 1: attn_wait_vmcnt<1>(); break;
+    case 2: attn_wait_vmcnt<2>(); break;
+    case 3: attn_wait_vmcnt<3>(); break;
+    case 4: attn_wait_vmcnt<4>(); break;
+    case 5: attn_wait_vmcnt<5>(); break;
+    case 6: attn_wait_vmcnt<6>(); break;
+    case 7: attn_wait_vmcnt<7>(); break;
+    default: attn_wait_vmcnt<8>(); break;
+  }
+}
+
+// one query block of pass A (the body of bwd_sweep_queries' loop; same arithmetic in the same order: same bits)
+template <bool DROP>
+__device__ __forceinline__ void bwd_query_block(const char* sQ, const char* sD, uint32_t aQ, uint32_t aD, uint32_t aLse,
+                                                uint32_t del_off, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], int kb,
+                                                int qb, const BwdCtx& cx, f32x16 (&dVt)[2], f32x16 (&dKt)[2]) {
+  const int lane = threadIdx.x & 63, r32 = lane & 31, h2 = lane >> 5;
+  const int tr_q = (lane >> 2) & 3;
+  const int tr_ch = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);  // + 4*db
+  const int tr_byte = (lane & 1) * 8;
+  const int pair = cx.pair, S = cx.S;
+  const uint32_t half_stride = cx.half_stride;
+  const float c_l2 = cx.c_l2, scale = cx.scale, keep_ds = cx.keep_ds;
+  const DropKey& dk = cx.dk;
+  (void)scale; (void)keep_ds; (void)half_stride; (void)pair; (void)S; (void)kb;
+  // every LDS read of the block goes out first (inline assembly: see above): the lse / delta quads and the sixteen
+  // transposing reads of the two output MFMA groups land behind the score MFMAs and the vector work
+  f32x4 l4[4], d4[4];
+  s16x4 rd[2][8];   // [s][4 db + {0: dO lo, 1: dO hi, 2: Q lo, 3: Q hi}]
+  {
+    const uint32_t a0 = aLse + (uint32_t)((qb * 32 + 4 * h2) * 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      asm volatile("ds_read_b128 %0, %1" : "=v"(l4[g]) : "v"(a0 + g * 32) : "memory");
+      asm volatile("ds_read_b128 %0, %1" : "=v"(d4[g]) : "v"(a0 + g * 32 + del_off) : "memory");
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q0 = qb * 32 + 16 * s + 4 * h2 + tr_q;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const uint32_t o_lo = (uint32_t)(du_off(q0, 4 * db + tr_ch) + tr_byte);
+        const uint32_t o_hi = (uint32_t)(du_off(q0 + 8, 4 * db + tr_ch) + tr_byte);
+        attn_tr_read_asm(rd[s][4 * db + 0], aD + o_lo);
+        attn_tr_read_asm(rd[s][4 * db + 1], aD + o_hi);
+        attn_tr_read_asm(rd[s][4 * db + 2], aQ + o_lo);
+        attn_tr_read_asm(rd[s][4 * db + 3], aQ + o_hi);
+      }
+    }
+  }
+  f32x16 sa, dp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + du_off(qb * 32 + r32, ks * 2 + h2));
+    const bf16x8 df = *reinterpret_cast<const bf16x8*>(sD + du_off(qb * 32 + r32, ks * 2 + h2));
+    sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], sa, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, vf[ks], dp, 0, 0, 0);
+  }
+  uint32_t hq[DROP ? 16 : 1];
+  if constexpr (DROP) {
+    uint32_t mine[8];
+    const int odd = lane & 1;
+    const uint32_t kp = (uint32_t)(kb * 16 + (r32 >> 1));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int query = qb * 32 + (i & 3) + 8 * (i >> 2) + 16 * odd + 4 * h2;
+      mine[i] = rvit_drop_hash(dk, (uint32_t)(pair * S + query) * half_stride + kp);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      hq[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[i], 0xA0 /* quad_perm [0,0,2,2] */, 0xf, 0xf, false);
+      hq[i + 8] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine[i], 0xF5 /* quad_perm [1,1,3,3] */, 0xf, 0xf, false);
+    }
+  }
+  const int half_shift = 16 * (lane & 1);
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(l4[0]), "+v"(l4[1]), "+v"(l4[2]), "+v"(l4[3]), "+v"(d4[0]), "+v"(d4[1]), "+v"(d4[2]), "+v"(d4[3])
+               :
+               : "memory");
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = 4 * g + e;
+      const float pe = __builtin_amdgcn_exp2f(fmaf(sa[r], c_l2, -l4[g][e]));
+      if constexpr (DROP) {
+        const bool keep = ((hq[r] >> half_shift) & 0xffffu) >= dk.thresh;
+        sa[r] = pe * (keep ? dk.scale : 0.f);
+        dp[r] = pe * fmaf(dp[r], keep ? keep_ds : 0.f, -d4[g][e]);
+      } else {
+        sa[r] = pe;
+        dp[r] = pe * fmaf(dp[r], scale, -d4[g][e]);
+      }
+    }
+  }
+  attn_tr_wait8(rd[0]);
+  attn_tr_wait8(rd[1]);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 pb, dsb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pb[j] = (bf16)sa[8 * s + j]; dsb[j] = (bf16)dp[8 * s + j]; }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const bf16x4 dlo = __builtin_bit_cast(bf16x4, rd[s][4 * db + 0]), dhi = __builtin_bit_cast(bf16x4, rd[s][4 * db + 1]);
+      const bf16x4 qlo = __builtin_bit_cast(bf16x4, rd[s][4 * db + 2]), qhi = __builtin_bit_cast(bf16x4, rd[s][4 * db + 3]);
+      const bf16x8 dOt = bf16x8{dlo[0], dlo[1], dlo[2], dlo[3], dhi[0], dhi[1], dhi[2], dhi[3]};
+      const bf16x8 Qt = bf16x8{qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+      dVt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dOt, pb, dVt[db], 0, 0, 0);
+      dKt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Qt, dsb, dKt[db], 0, 0, 0);
+    }
+  }
+}
+
+template <int NKB, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_pipe_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ O,
+                                                               const bf16* __restrict__ dO, const float* __restrict__ lse,
+                                                               bf16* __restrict__ dqkv, int total_pairs, int S, int H,
+                                                               long ldq, long ldo, long lddo, long lddq, float scale,
+                                                               DropKey dk) {
+  static_assert(NKB >= 5 && NKB <= 8, "one (image, head) pair per workgroup, eight waves");
+  constexpr int SP = 32 * NKB;
+  constexpr int TILE = SP * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sQ = smem;
+  char* const sK = sQ + TILE;
+  char* const sV = sK + TILE;
+  char* const sD = sV + TILE;
+  float* const sLse = reinterpret_cast<float*>(sD + TILE);
+  float* const sDel = sLse + SP;
+  typedef __attribute__((address_space(3))) const char lds_cchar;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_cchar*)smem;
+  const uint32_t aQ = lds0, aD = lds0 + 3 * TILE;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int E = H * 64;
+  const int pair = blockIdx.x;   // (an XCD-aware pair order, heads of an image on one XCD, measured no different)
+  const int b = pair / H, h = pair - b * H;
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const float c_l2 = scale * 1.44269504088896340736f;
+  const uint32_t half_stride = (uint32_t)((S + 1) >> 1);
+  const float keep_ds = dk.scale * scale;
+  ATTN_STAMP(0);
+
+  // ---- the global rows for delta / lse (oldest requests), then every LDS-DMA piece in the order of use ----------------
+  constexpr int DIT = (SP * 8 + 511) / 512;   // (row, chunk) items per thread
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 dreg[DIT], oreg[DIT];
+  float lreg[DIT];
+  const bf16* const dbase = dO + (long)b * S * lddo + h * 64;
+  const bf16* const obase = O + (long)b * S * ldo + h * 64;
+  // As inline assembly: loads the compiler can see are waited for with s_waitcnt vmcnt(0) at their first use once an
+  // LDS-DMA has been issued behind them (its wait-count pass gives up counting), which would drain every piece below
+  // before pass A starts.  Rows >= S read row 0 (a valid address) and are zeroed / set to +inf afterwards.
+#pragma unroll
+  for (int it = 0; it < DIT; ++it) {
+    const int id = t + it * 512, row = id >> 3, c = id & 7;
+    const int rsafe = row < S ? row : 0;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dreg[it]) : "v"(dbase + (long)rsafe * lddo + c * 8) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(oreg[it]) : "v"(obase + (long)rsafe * ldo + c * 8) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "=v"(lreg[it]) : "v"(lse + (long)pair * S + rsafe) : "memory");
+  }
+  const bf16* const qbase = qkv + (long)b * S * ldq + h * 64;
+  {
+    const bool second = wave >= 4;   // waves 0-3: K / Q, waves 4-7: V / dO
+    const int sub = wave & 3;
+    const bf16* kv_src = qbase + (second ? 2 * E : E);
+    char* kv_img = second ? sV : sK;
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) attn_stage_rows(kv_src, ldq, S, kv_img, j * 4 + sub, lane);
+    const bf16* qd_src = second ? dbase : qbase;
+    const long qd_ld = second ? lddo : ldq;
+    char* qd_img = second ? sD : sQ;
+#pragma unroll
+    for (int j = 0; j < NKB; ++j) attn_stage_rows(qd_src, qd_ld, S, qd_img, j * 4 + sub, lane);
+  }
+  // the dO / O / lse rows are back; all 2 NKB pieces still in flight
+#pragma unroll
+  for (int it = 0; it < DIT; ++it)
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(dreg[it]), "+v"(oreg[it]), "+v"(lreg[it]) : "n"(2 * NKB) : "memory");
+#pragma unroll
+  for (int it = 0; it < DIT; ++it) {
+    const int id = t + it * 512, row = id >> 3, c = id & 7;
+    const bool rok = row < S;
+    const uint4 dv = rok ? make_uint4(dreg[it][0], dreg[it][1], dreg[it][2], dreg[it][3]) : zero4;
+    const uint4 ov = make_uint4(oreg[it][0], oreg[it][1], oreg[it][2], oreg[it][3]);
+    float d = bf16_lo(dv.x) * bf16_lo(ov.x) + bf16_hi(dv.x) * bf16_hi(ov.x) +
+              bf16_lo(dv.y) * bf16_lo(ov.y) + bf16_hi(dv.y) * bf16_hi(ov.y) +
+              bf16_lo(dv.z) * bf16_lo(ov.z) + bf16_hi(dv.z) * bf16_hi(ov.z) +
+              bf16_lo(dv.w) * bf16_lo(ov.w) + bf16_hi(dv.w) * bf16_hi(ov.w);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (c == 0 && row < SP) {
+      sDel[row] = d * scale;
+      sLse[row] = row < S ? lreg[it] * 1.44269504088896340736f : INFINITY;   // rows >= S: +inf -> P = 0
+    }
+  }
+  // this wave's K / V pieces have landed, its sDel / sLse stores are done; then everybody's (a raw barrier:
+  // __syncthreads() would also wait for every piece still in flight)
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NKB) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  ATTN_STAMP(1);
+  ATTN_STAMP(2);
+
+  const int r32 = lane & 31, h2 = lane >> 5;
+  const BwdCtx cx{pair, S, half_stride, c_l2, scale, keep_ds, dk};
+  // ================================ pass A: dK, dV ================================================
+  {
+    const int kb = wave;
+    const bool active = kb < NKB;
+    bf16x8 kf[4], vf[4];
+    f32x16 dVt[2], dKt[2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(sK + du_off((active ? kb : 0) * 32 + r32, ks * 2 + h2));
+      vf[ks] = *reinterpret_cast<const bf16x8*>(sV + du_off((active ? kb : 0) * 32 + r32, ks * 2 + h2));
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dVt[db][r] = 0.f; dKt[db][r] = 0.f; }
+#pragma unroll 1
+    for (int qb = 0; qb < NKB; ++qb) {
+      attn_wait_vmcnt_rt(NKB - 1 - qb);   // this wave's piece of query block qb has landed
+      __builtin_amdgcn_s_barrier();       // everybody's
+      asm volatile("" ::: "memory");
+      if (active) bwd_query_block<DROP>(sQ, sD, aQ, aD, lds0 + 4 * TILE, (uint32_t)(SP * 4), kf, vf, kb, qb, cx, dVt, dKt);
+    }
+    ATTN_STAMP(3);
+    if (active) {
+      const int key = kb * 32 + r32;
+      const bool k_ok = key < S;
+      bf16* krow = dqkv + ((long)b * S + (k_ok ? key : 0)) * lddq + E + h * 64;
+      attn_store_row(krow, dKt, h2, 1.0f, k_ok);
+      attn_store_row(krow + E, dVt, h2, 1.0f, k_ok);
+    }
+  }
+  ATTN_STAMP(4);
+  // ================================ pass B: dQ (everything is in LDS) ==============================
+  if (wave < NKB) {
+    const int qb = wave;
+    bf16x8 qf[4], df[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(sQ + du_off(qb * 32 + r32, ks * 2 + h2));
+      df[ks] = *reinterpret_cast<const bf16x8*>(sD + du_off(qb * 32 + r32, ks * 2 + h2));
+    }
+    const float lse_q = sLse[qb * 32 + r32];
+    const float del_q = sDel[qb * 32 + r32];
+    f32x16 dQt[2];
+    bwd_sweep_keys<NKB, DROP>(sK, sV, qf, df, lse_q, del_q, qb, cx, dQt);
+    ATTN_STAMP(5);
+    const int query = qb * 32 + r32;
+    const bool q_ok = query < S;
+    attn_store_row(dqkv + ((long)b * S + (q_ok ? query : 0)) * lddq + h * 64, dQt, h2, 1.0f, q_ok);
+  }
+  ATTN_STAMP(6);
+}
+
 // Waves per workgroup of the backward kernel: its four LDS images allow only one workgroup per CU once S > 128
 // (NKB >= 5), so those cases run 8 waves (two per SIMD, one round over the <= 8 key / query blocks).
 template <int NKB> constexpr int bwd_waves() { return NKB >= 5 ? 8 : 4; }
@@ -831,6 +1119,17 @@ int launch_attn_bwd_t(const bf16* qkv, const bf16* O, const bf16* dO, const floa
   const int total = B * H;
   constexpr int PAIRS = NKB >= 4 ? 1 : 4 / NKB;
   constexpr int LDS = bwd_image_bytes<NKB>();
+  if constexpr (NKB >= 5) {
+    static const bool pipe = [] { const char* e = getenv("RVIT_ATTN_BWD_PIPE"); return !e || atoi(e) != 0; }();
+    if (pipe) {
+      static RvitLdsLimit lim_p;
+      if (const int rc = lim_p.ensure({(const void*)attn_bwd_pipe_kernel<NKB, DROP>}, LDS, "attn_bwd")) return rc;
+      hipLaunchKernelGGL((attn_bwd_pipe_kernel<NKB, DROP>), dim3((unsigned)total), dim3(512), LDS, st, qkv, O, dO, lse, dqkv,
+                         total, S, H, ldq, ldo, lddo, lddq, scale, dk);
+      RVIT_CHECK_LAUNCH("attn_bwd");
+      return RVIT_OK;
+    }
+  }
   static RvitLdsLimit lim;
   if (const int rc = lim.ensure({(const void*)attn_bwd_kernel<NKB, DROP>}, LDS, "attn_bwd")) return rc;
   const unsigned grid = (unsigned)((total + PAIRS - 1) / PAIRS);
