@@ -16,6 +16,7 @@
 // left in the K loop (beside LDS-DMA hipcc waits vmcnt(0) for any of those: cdna_hip_programming.md section 5).
 // Epilogue in registers (v_permlane16_swap: 8 consecutive columns per lane), forms fixed at compile time; the MX copy of
 // the output takes the block maximum over the four lanes that hold a 32-column block (lane rows fq = 0..3).
+#include <stdlib.h>
 #include "common.h"
 #include "rvit_internal.h"
 #include "mx_common.h"
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(512) void gemm_mx8p_kernel(const MxGemmArgs p) {
 int rvit_gemm_mx8p_mode(const MxGemmArgs& a) {
   if ((a.K & 255) != 0 || !a.bias || a.act == RVIT_ACT_RELU) return -1;   // an even number of K tiles, bias always
   const long t256 = ((a.M + 255) / 256) * (long)((a.N + 255) / 256);
-  if (t256 < 512) return -1;
+  static const long min_tiles = [] { const char* e = getenv("RVIT_MX8P_MIN_TILES"); return e ? atol(e) : 512L; }();   // A/B runs
+  if (t256 < min_tiles) return -1;
   const int gelu = a.act == RVIT_ACT_GELU;
   if (a.C && !a.c_f32 && !a.R && !a.Cq && !gelu) return X8F_C;                                  // in_proj: bf16 out
   if (a.C && a.c_f32 && a.R && a.r_f32 && !a.Cq && !gelu) return X8F_C | X8F_CF32 | X8F_R32;    // out_proj / linear2
