@@ -157,8 +157,14 @@ def kernel_roofline(kernels, peak, steps):
         d = fam.setdefault(f, {"ms": 0.0, "flops": 0.0})
         d["ms"] += k["ms"]
         d["flops"] += k["flops"]
+    # every family is priced against the peak of the MFMA it runs on: only the block-scaled MX GEMMs reach the fp8 peak
+    # (the MX-fp8 mode's attention - bf16 MFMA, or un-scaled fp8 at the same rate - and its patch-embedding conv are not)
+    def fam_peak(f):
+        mx = f == "gemm" and any(n.startswith("gemm_mx") for n in mf)   # un-scaled fp8 MFMAs run at the bf16 rate
+        return peak if (mx or peak == BF16_MFMA_PEAK_TFLOPS) else BF16_MFMA_PEAK_TFLOPS
     split = {f: {"ms_per_step": round(d["ms"] / steps, 3), "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 1),
-                 "frac_of_peak": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / peak, 4)} for f, d in sorted(fam.items())}
+                 "peak": fam_peak(f), "frac_of_peak": round(d["flops"] / (d["ms"] * 1e-3) / 1e12 / fam_peak(f), 4)}
+             for f, d in sorted(fam.items())}
     return roof, split
 
 
