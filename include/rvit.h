@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 23
+#define RVIT_ABI_VERSION 24
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -419,6 +419,17 @@ int rvit_attn_fwd_mx(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out_
 int rvit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
                   int H, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, float drop_p,
                   uint64_t drop_seed, void* stream);
+
+/* rvit_attn_fwd / rvit_attn_bwd for the other head dims the reference's constructor accepts (train_vit.py:76-111 builds
+ * nn.TransformerEncoderLayer(d_model=embed_dim, nhead=num_heads) for any embed_dim % num_heads == 0; torch
+ * functional.py:6623-6631): head_dim in {16, 32, 48, 96, 128}, S <= 256.  Same layouts with column blocks of width
+ * H*head_dim, same dropout site indexing (rvit_dropout_mask replays it), same lse.  `scale` is given by the caller
+ * (torch: head_dim^-0.5) and must be positive.  head_dim 64 stays on rvit_attn_fwd / rvit_attn_bwd. */
+int rvit_attn_dh_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int head_dim, int64_t ldq, int64_t ldo,
+                     float scale, float drop_p, uint64_t drop_seed, void* stream);
+int rvit_attn_dh_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
+                     int H, int head_dim, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, float drop_p,
+                     uint64_t drop_seed, void* stream);
 
 /* Cross-entropy with label smoothing, mean over the batch, value and gradient in one pass
  * (nn.CrossEntropyLoss(label_smoothing=...), train_vit.py:894,937).

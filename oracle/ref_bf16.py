@@ -66,9 +66,9 @@ def forward_bf16_emulated(sd: dict, x: torch.Tensor, cfg: dict, features_only: b
         q = f"transformer.layers.{i}."
         ln = _r(F.layer_norm(xs, (E,), sd[q + "norm1.weight"], sd[q + "norm1.bias"]))
         qkv = _r(ln @ _r(sd[q + "self_attn.in_proj_weight"]).T + sd[q + "self_attn.in_proj_bias"])
-        qh, kh, vh = [u.reshape(B, S, H, 64).transpose(1, 2) for u in qkv.split(E, -1)]
+        qh, kh, vh = [u.reshape(B, S, H, E // H).transpose(1, 2) for u in qkv.split(E, -1)]
         sc = qh @ kh.transpose(-1, -2)
-        pe = torch.exp((sc - sc.amax(-1, keepdim=True)) * 0.125)
+        pe = torch.exp((sc - sc.amax(-1, keepdim=True)) * (E // H) ** -0.5)   # 0.125 at head_dim 64
         att = _r((_r(pe) @ vh) / pe.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, S, E)
         xs = xs + att @ _r(sd[q + "self_attn.out_proj.weight"]).T + sd[q + "self_attn.out_proj.bias"]
         ln = _r(F.layer_norm(xs, (E,), sd[q + "norm2.weight"], sd[q + "norm2.bias"]))

@@ -31,13 +31,20 @@ def _pair(cfg, seed, dev):
     return m.to(dev).eval(), ref.eval(), sd
 
 
-# (name, config, batch, fixed logit bound = 1.5 x measured: 0.163 / 0.116 / 0.444 / 0.079 / 0.117)
+# (name, config, batch, fixed logit bound = 1.5 x measured: 0.163 / 0.116 / 0.444 / 0.079 / 0.117; the head-dim cases
+# 0.238 / 0.209 / 0.066 / 0.073 / 0.080)
 CASES = [
     ("R-hybrid", dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="resnet18"), 8, 0.25),
     ("legacy-hybrid", dict(num_classes=11, embed_dim=384, num_heads=6, num_layers=6, dropout=0.1, backbone="resnet18"), 3, 0.18),
     ("resnet34", dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=2, dropout=0.1, backbone="resnet34"), 2, 0.67),
     ("vit-small-patch16", dict(num_classes=11, embed_dim=256, num_heads=4, num_layers=4, dropout=0.1, backbone="patch16"), 5, 0.12),
     ("vit-B-scale", dict(num_classes=11, embed_dim=768, num_heads=12, num_layers=12, dropout=0.1, backbone="patch16"), 2, 0.18),
+    # head dims other than 64 (csrc/attn_dh.hip): the reference's constructor takes any embed_dim % num_heads == 0
+    ("hybrid-H8-dh32", dict(num_classes=11, embed_dim=256, num_heads=8, num_layers=4, dropout=0.1, backbone="resnet18"), 8, 0.36),
+    ("hybrid-H2-dh128", dict(num_classes=11, embed_dim=256, num_heads=2, num_layers=4, dropout=0.1, backbone="resnet18"), 4, 0.32),
+    ("patch16-H4-dh96", dict(num_classes=11, embed_dim=384, num_heads=4, num_layers=3, dropout=0.1, backbone="patch16"), 3, 0.10),
+    ("patch16-H8-dh16", dict(num_classes=11, embed_dim=128, num_heads=8, num_layers=3, dropout=0.1, backbone="patch16"), 3, 0.11),
+    ("patch16-H4-dh48", dict(num_classes=11, embed_dim=192, num_heads=4, num_layers=3, dropout=0.1, backbone="patch16"), 3, 0.12),
 ]
 
 

@@ -59,6 +59,13 @@ CASES = [
     # BASELINE configs[3] at its own size: ViT-B/16-scale (E768 / H12 / L12, 86 M parameters), one training step
     ("vit-B-scale", dict(num_classes=11, embed_dim=768, num_heads=12, num_layers=12, dropout=0.0, backbone="patch16"),
      2, 0.06, 0.995),
+    # head dims other than 64 (csrc/attn_dh.hip forward + backward inside a whole training step)
+    ("patch16-H8-dh32", dict(num_classes=11, embed_dim=256, num_heads=8, num_layers=3, dropout=0.0, backbone="patch16"),
+     3, 0.06, 0.995),
+    ("patch16-H2-dh128", dict(num_classes=11, embed_dim=256, num_heads=2, num_layers=3, dropout=0.0, backbone="patch16"),
+     3, 0.06, 0.995),
+    ("patch16-H4-dh48", dict(num_classes=11, embed_dim=192, num_heads=4, num_layers=2, dropout=0.0, backbone="patch16"),
+     3, 0.06, 0.995),
 ]
 
 

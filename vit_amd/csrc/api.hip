@@ -447,6 +447,18 @@ int rvit_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
                             (hipStream_t)stream);
 }
 
+int rvit_attn_dh_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int head_dim, int64_t ldq, int64_t ldo,
+                     float scale, float drop_p, uint64_t drop_seed, void* stream) {
+  return rvit_attn_dh_fwd_impl(qkv, out, lse, B, S, H, head_dim, ldq, ldo, scale, drop_p, drop_seed, (hipStream_t)stream);
+}
+
+int rvit_attn_dh_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
+                     int H, int head_dim, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, float drop_p,
+                     uint64_t drop_seed, void* stream) {
+  return rvit_attn_dh_bwd_impl(qkv, out, dout, lse, dqkv, B, S, H, head_dim, ldq, ldo, lddo, lddq, scale, drop_p,
+                               drop_seed, (hipStream_t)stream);
+}
+
 int rvit_ce_loss(const float* logits, int64_t ldl, const int64_t* labels, float* loss_sum, float* dlogits,
                  int64_t lddl, void* dlogits_bf16, int64_t lddb, int B, int C, int C_pad, float label_smoothing,
                  float grad_scale, void* stream) {

@@ -196,6 +196,11 @@ int rvit_pointwise_impl(const void* x, const void* w, const float* scale, const 
                         long M, int K, int N, int act, hipStream_t st);
 int rvit_conv3x3s2_rgb_impl(const float* x, const float* w, const float* scale, const float* bias, void* out, int B, int H,
                             int W, int Cout, int act, hipStream_t st);
+int rvit_attn_dh_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, int H, int Dh, long ldq, long ldo,
+                          float scale, float drop_p, uint64_t drop_seed, hipStream_t st);
+int rvit_attn_dh_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
+                          int Dh, long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,
+                          hipStream_t st);
 int rvit_attn16_impl(const void* qkv, void* out, int B, int S, int H, long ldq, long ldo, float scale, hipStream_t st);
 int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
                        long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,

@@ -71,6 +71,8 @@ class Engine:
             raise ValueError(f"unknown inference precision {precision!r}; choose 'bf16' or 'mxfp8'")
         if precision == "mxfp8" and (self.m.embed_dim % 128 != 0):
             raise ValueError("mxfp8 needs embed_dim to be a multiple of 128")
+        if precision == "mxfp8" and self.m.embed_dim // self.m.num_heads != 64:
+            raise NotImplementedError("mxfp8: the MX-output attention kernels are built for head_dim 64 only")
         if precision != self.precision:
             self.precision = precision
             self._pack = None

@@ -14,6 +14,7 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
+from . import ops
 from .engine import Engine
 
 
@@ -246,9 +247,12 @@ class CNNViTHybrid(nn.Module):
             # features_only efficientnet returns 320 / 352 channels at stride 32, not the 1280 / 1408 of its classifier
             # head that train_vit.py:72-73 feeds to patch_embed
             raise NotImplementedError(f"backbone {backbone!r}: no HIP stem yet (out of scope, SURVEY.md §8f #4)")
-        if embed_dim % num_heads != 0 or embed_dim // num_heads != 64:
-            raise NotImplementedError("HIP attention kernel supports head_dim 64 only "
-                                      f"(embed_dim={embed_dim}, num_heads={num_heads})")
+        if embed_dim % num_heads != 0:
+            # nn.MultiheadAttention's own assertion (torch activation.py: "embed_dim must be divisible by num_heads")
+            raise AssertionError("embed_dim must be divisible by num_heads")
+        if embed_dim // num_heads not in ops.ATTN_HEAD_DIMS:
+            raise NotImplementedError(f"HIP attention kernels cover head_dim {ops.ATTN_HEAD_DIMS} "
+                                      f"(embed_dim={embed_dim}, num_heads={num_heads} gives {embed_dim // num_heads})")
         _, cnn_out, feat = self.BACKBONES[backbone]
         self.num_classes, self.embed_dim, self.num_heads, self.num_layers = num_classes, embed_dim, num_heads, num_layers
         self.dropout = float(dropout)

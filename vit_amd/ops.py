@@ -540,21 +540,37 @@ def layernorm_mx(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, q: to
     return q, scales
 
 
+ATTN_HEAD_DIMS = (16, 32, 48, 64, 96, 128)
+
+
+def _attn_head_dim(W3: int, Wo: int, H: int, what: str) -> int:
+    """Head dim from the packed widths; 64 runs csrc/attn.hip, the others csrc/attn_dh.hip."""
+    Dh = Wo // H if H > 0 else 0
+    if H <= 0 or Wo != H * Dh or W3 != 3 * Wo or Dh not in ATTN_HEAD_DIMS:
+        raise ValueError(f"{what}: widths {W3} / {Wo} do not give a supported head_dim for H={H} {ATTN_HEAD_DIMS}")
+    return Dh
+
+
 def attention(qkv: torch.Tensor, out: torch.Tensor, B: int, S: int, H: int, lse: Optional[torch.Tensor] = None,
               scale: Optional[float] = None, drop_p: float = 0.0, drop_seed: int = 0) -> torch.Tensor:
-    """qkv bf16 [B*S, 3*H*64] (q|k|v), out bf16 [B*S, H*64]; softmax(q k^T scale) v per head."""
+    """qkv bf16 [B*S, 3*H*Dh] (q|k|v), out bf16 [B*S, H*Dh]; softmax(q k^T scale) v per head (scale: Dh^-0.5)."""
     _need_cuda(qkv, out, lse)
     T, W3, ldq = _rows2d(qkv, "attention qkv")
     To, Wo, ldo = _rows2d(out, "attention out")
-    if T != B * S or To != T or W3 != 3 * H * 64 or Wo != H * 64:
+    if T != B * S or To != T:
         raise ValueError(f"attention: shapes {tuple(qkv.shape)} / {tuple(out.shape)} do not match B={B} S={S} H={H}")
+    Dh = _attn_head_dim(W3, Wo, H, "attention")
     if qkv.dtype != BF16 or out.dtype != BF16:
         raise TypeError("attention: bf16 only")
     _vec_f32(lse, B * H * S, "attention: lse")
-    sc = (1.0 / 8.0) if scale is None else float(scale)
-    with _Span("attn_fwd", 4 * B * H * S * S * 64, _nbytes(qkv, out, lse)):
-        check(_lib.load().rvit_attn_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, S, H, ldq, ldo, sc,
-                                        float(drop_p), int(drop_seed), _stream()), "rvit_attn_fwd")
+    sc = Dh ** -0.5 if scale is None else float(scale)
+    with _Span("attn_fwd", 4 * B * H * S * S * Dh, _nbytes(qkv, out, lse)):
+        if Dh == 64:
+            check(_lib.load().rvit_attn_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, S, H, ldq, ldo, sc,
+                                            float(drop_p), int(drop_seed), _stream()), "rvit_attn_fwd")
+        else:
+            check(_lib.load().rvit_attn_dh_fwd(qkv.data_ptr(), out.data_ptr(), _ptr(lse), B, S, H, Dh, ldq, ldo, sc,
+                                               float(drop_p), int(drop_seed), _stream()), "rvit_attn_dh_fwd")
     return out
 
 
@@ -1095,15 +1111,20 @@ def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse:
     _, Wo, ldo = _rows2d(out, "attention_bwd out")
     _, Wd, lddo = _rows2d(dout, "attention_bwd dout")
     Tq, Wq, lddq = _rows2d(dqkv, "attention_bwd dqkv")
-    if T != B * S or Tq != T or W3 != 3 * H * 64 or Wq != W3 or Wo != H * 64 or Wd != Wo \
-            or any(t.dtype != BF16 for t in (qkv, out, dout, dqkv)):
+    if T != B * S or Tq != T or Wq != W3 or Wd != Wo or any(t.dtype != BF16 for t in (qkv, out, dout, dqkv)):
         raise ValueError("attention_bwd: shape/dtype mismatch")
+    Dh = _attn_head_dim(W3, Wo, H, "attention_bwd")
     _vec_f32(lse, B * H * S, "attention_bwd: lse")
-    sc = (1.0 / 8.0) if scale is None else float(scale)
-    with _Span("attn_bwd", 10 * B * H * S * S * 64, _nbytes(qkv, out, dout, dqkv)):
-        check(_lib.load().rvit_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
-                                        dqkv.data_ptr(), B, S, H, ldq, ldo, lddo, lddq, sc, float(drop_p),
-                                        int(drop_seed), _stream()), "rvit_attn_bwd")
+    sc = Dh ** -0.5 if scale is None else float(scale)
+    with _Span("attn_bwd", 10 * B * H * S * S * Dh, _nbytes(qkv, out, dout, dqkv)):
+        if Dh == 64:
+            check(_lib.load().rvit_attn_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                            dqkv.data_ptr(), B, S, H, ldq, ldo, lddo, lddq, sc, float(drop_p),
+                                            int(drop_seed), _stream()), "rvit_attn_bwd")
+        else:
+            check(_lib.load().rvit_attn_dh_bwd(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(),
+                                               dqkv.data_ptr(), B, S, H, Dh, ldq, ldo, lddo, lddq, sc, float(drop_p),
+                                               int(drop_seed), _stream()), "rvit_attn_dh_bwd")
     return dqkv
 
 
