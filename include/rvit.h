@@ -82,7 +82,8 @@ const char* rvit_last_error(void);
  *   drop_mode / drop_p / drop_seed: dropout in the epilogue (above); element index = C row * N + column
  *   tile: 0 = automatic tile choice, 1/2/3/4 force 256x64 / 128x64 / 64x64 / 256x256 of sixteen 64x64 waves, 5 the
  *   eight-wave 256x256 kernel with the four-phase K tile (csrc/gemm8p.hip: plain A operand, 16-byte aligned rows, K % 64
- *   == 0; what products of >= 512 such tiles with K >= 512 run: the ViT-B / ViT-L Linears); for testing: every tile
+ *   == 0; what products of >= 512 such tiles with K >= 512 run: the ViT-B / ViT-L Linears), 6 / 7 = 256x128 on sixteen /
+ *   128x128 on eight waves (7: implicit-GEMM convs with N % 128 == 0 that fill the chip); for testing: every tile
  *   contracts K in the same order, so the choice never changes a bit of the result. */
 int rvit_gemm_bf16(const void* A, int64_t lda, int a_row_group, int a_row_extra, const void* B, int64_t ldb, void* C,
                    int64_t ldc, int c_dtype, int64_t M, int N, int K, const float* scale, const float* bias,

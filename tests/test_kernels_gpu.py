@@ -23,7 +23,7 @@ def _close(got, ref, rtol, atol, what=""):
     assert bad == 0, f"{what}: {bad}/{err.numel()} out of tolerance, max err {err.max().item():.4g}"
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(300, 256, 256), (128, 128, 64), (1000, 768, 200), (77, 11, 128), (64, 1024, 264)])
 def test_gemm_plain(dev, M, N, K, tile):
     from vit_amd import ops
@@ -300,6 +300,25 @@ def test_attention_asymmetric_exact(dev):
     assert torch.equal(out.float().cpu(), ref), "attention picks wrong V rows/columns"
 
 
+@pytest.mark.parametrize("cin,cout,hw,k", [(64, 128, 56, 3), (64, 128, 56, 1), (128, 256, 28, 1), (256, 512, 14, 1)])
+def test_conv_128x128_tile_bit_identical(dev, cin, cout, hw, k):
+    """The 128x128 tile (tile 7: what the stride-2 convs with N % 128 == 0 run once they fill the chip) contracts K in
+    the order of the 256x64 tile: same bits, so the choice by batch size cannot change a frame's result.  B = 100 is a
+    batch the dispatcher sends to it by itself (tile 0)."""
+    from vit_amd import ops
+    B = 100
+    g = torch.Generator().manual_seed(cin + hw + k)
+    x = _bf(torch.randn(B, hw, hw, cin, generator=g)).to(dev)
+    w = _bf(torch.randn(cout, k * k * cin, generator=g) / math.sqrt(k * k * cin)).to(dev)
+    scale, bias = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    outs = []
+    for tile in (1, 7, 0):
+        o = torch.empty(B, hw // 2, hw // 2, cout, dtype=torch.bfloat16, device=dev)
+        ops.conv2d(x, w, o, kh=k, kw=k, stride=2, pad=k // 2, scale=scale, bias=bias, act="relu", tile=tile)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def _conv_ref(x_nhwc, w_ohwi, stride, pad):
     return F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w_ohwi.float().permute(0, 3, 1, 2), None, stride, pad)
 
@@ -307,7 +326,7 @@ def _conv_ref(x_nhwc, w_ohwi, stride, pad):
 @pytest.mark.parametrize("cin,cout,hw,k,stride,pad", [(64, 64, 56, 3, 1, 1), (64, 128, 56, 3, 2, 1),
                                                       (64, 128, 56, 1, 2, 0), (256, 512, 14, 3, 2, 1),
                                                       (512, 512, 7, 3, 1, 1), (128, 128, 28, 3, 1, 1)])
-@pytest.mark.parametrize("tile", [0, 3])
+@pytest.mark.parametrize("tile", [0, 3, 7])
 def test_conv_nhwc(dev, cin, cout, hw, k, stride, pad, tile):
     from vit_amd import ops
     B = 3

@@ -395,10 +395,17 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   // tiles (layer4, B=256) the chip is too empty and 256x64 wins again (profiles/r02_stride2_tiles.txt).  Same bits.
   const bool big_conv = a.mode == 1 && !a.transposed && (a.N & 255) == 0 && a.K >= 1024 && t256 >= 192;
   const bool big = big_plain || big_conv;
+  // the other implicit-GEMM convs with N a multiple of 128 (layer2's stride-2 3x3 conv, the 1x1 downsample convs): a
+  // 128x128 tile on eight waves, two workgroups per CU, fetches the gathered A tile once per 128 output columns:
+  // B=512 layer2.0.conv1 147 -> 118 us, the three downsample convs 47 / 31 / 23 -> 45 / 29 / 21 us; 256x128 on sixteen
+  // waves 135 us (profiles/r03_session2_notes.txt #7).  Same K order, same bits.
+  const bool mid_conv = a.mode == 1 && !a.transposed && !big_conv && (a.N & 127) == 0 &&
+                        ((a.M + 127) / 128) * (long)(a.N / 128) >= 512;
   int cfg;
   if (forced) cfg = forced;
   else if (a.mode == 0 && a.K >= 512 && t256 >= 512 && rvit_gemm8p_ok(a)) cfg = 5;   // eight waves, four-phase K tile (gemm8p.hip): 0.92-1.13 vs 0.59-0.90 PFLOP/s on the ViT-B Linears, same bits
   else if (big) cfg = 4;
+  else if (mid_conv) cfg = 7;
   else if (((a.M + 255) / 256) * n64 >= 384) cfg = 1;
   else if (((a.M + 127) / 128) * n64 >= 256) cfg = 2;
   else cfg = 3;
@@ -408,6 +415,8 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     case 3: return launch_cfg<64, 64, 2, 1, 2>(a, stream);
     case 4: return launch_cfg<256, 256, 4, 4, 2>(a, stream);
     case 5: return rvit_gemm8p(a, stream);
+    case 6: return launch_cfg<256, 128, 8, 2, 2>(a, stream);
+    case 7: return launch_cfg<128, 128, 4, 2, 2>(a, stream);
     // 64x64 wave tiles (<256,64,4>, <128,64,2>, <512,64,8>: fewer LDS reads per MFMA) measured 20-35 % slower:
     // this loop is latency-bound and wants the 16 waves per CU (profiles/r01_tile_sweep_wave64.txt)
     default: rvit_set_error("gemm: unknown tile config %d", cfg); return RVIT_EINVAL;
