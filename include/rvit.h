@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 24
+#define RVIT_ABI_VERSION 25
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -488,6 +488,18 @@ int rvit_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float
 int rvit_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* fwd_sums, const float* bwd_sums,
                       const float* gamma, void* dy, void* dz_masked, float* dgamma, float* dbeta, int64_t M, int C,
                       float eps, int relu, void* stream);
+
+/* rvit_bn_bwd_reduce / rvit_bn_bwd_apply (relu = 2) for a BatchNorm whose ReLU output went through rvit_bn_apply_pool
+ * (the stem's bn1 -> relu -> 3x3 / stride-2 max-pool; timm resnet18 behind train_vit.py:87,145): dz is not read from
+ * the [B,H,W,C] map rvit_maxpool3x3s2_bwd_nhwc would write but gathered from the pooled map's gradient dpool
+ * [B,Ho,Wo,C] and the argmax taps.  The same bits as that call followed by the plain entries (same fp32 sum over the
+ * windows, same bf16 rounding), without the map's round trip through HBM and without the launch.  B*H*W < 2^24. */
+int rvit_bn_bwd_reduce_pool(const void* dpool, const void* argmax, const void* relu_mask, const void* y,
+                            const float* fwd_sums, int B, int H, int W, int C, float eps, float* bwd_sums, void* workspace,
+                            void* stream);
+int rvit_bn_bwd_apply_pool(const void* dpool, const void* argmax, const void* relu_mask, const void* y,
+                           const float* fwd_sums, const float* bwd_sums, const float* gamma, void* dy, float* dgamma,
+                           float* dbeta, int B, int H, int W, int C, float eps, void* stream);
 
 /* Backward of rvit_maxpool3x3s2_nhwc from the recorded argmax taps; dx bf16 [B,H,W,C]. */
 int rvit_maxpool3x3s2_bwd_nhwc(const void* dpool, const void* argmax, void* dx, int B, int H, int W, int C,

@@ -503,6 +503,43 @@ def test_bn_apply_pool_fused(dev, B, H, W, C):
     assert (p.float().cpu() - pr).abs().max().item() <= 2.0 ** -7 * max(1.0, pr.abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 112, 112, 64), (2, 15, 9, 64), (5, 8, 8, 128), (1, 7, 30, 16)])
+@pytest.mark.parametrize("ordered", [False, True])
+def test_bn_bwd_behind_maxpool_fused(dev, B, H, W, C, ordered):
+    """bn_bwd_pool (the max-pool's gradient gathered inside the two BatchNorm backward passes) against
+    maxpool3x3s2_bwd + bn_bwd(relu_mask=...): dy bit-identical; the sums bit-identical with the ordered reductions
+    (the atomic form differs in its arrival order from run to run).  Odd sizes: clipped windows, rows in one window only."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(B * H + W + C)
+    y = (torch.randn(B, H, W, C, generator=g) * 1.3 - 0.1).bfloat16().to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    ws = ops.bn_workspace(dev) if ordered else None
+    fs = torch.zeros(2 * C, device=dev)
+    ops.bn_stats(y, fs, workspace=ws)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    pooled = torch.empty(B, Ho, Wo, C, dtype=torch.bfloat16, device=dev)
+    arg = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=dev)
+    mask = torch.empty(B * H * W * (C // 8), dtype=torch.uint8, device=dev)
+    ops.bn_apply_pool(y, fs, gamma, beta, pooled, arg, mask, eps=1e-5)
+    dpool = torch.randn(B, Ho, Wo, C, generator=g).bfloat16().to(dev)
+
+    dx = torch.empty_like(y)
+    ops.maxpool3x3s2_bwd(dpool, arg, dx)
+    bs1, dg1, db1 = torch.zeros(2 * C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy1 = torch.empty_like(y)
+    ops.bn_bwd(dx, None, y, fs, bs1, gamma, dy1, dg1, db1, eps=1e-5, relu=True, relu_mask=mask, workspace=ws)
+
+    bs2, dg2, db2 = torch.zeros(2 * C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dy2 = torch.full_like(y, float("nan"))
+    ops.bn_bwd_pool(dpool, arg, mask, y, fs, bs2, gamma, dy2, dg2, db2, eps=1e-5, workspace=ws)
+    if ordered:
+        assert torch.equal(bs1, bs2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+        assert torch.equal(dy1, dy2)
+    else:
+        assert torch.allclose(bs1, bs2, rtol=1e-4, atol=1e-3)
+        assert (dy1.float() - dy2.float()).abs().max().item() <= 2e-2 * max(1.0, dy1.float().abs().max().item())
+
+
 @pytest.mark.parametrize("B,Hy,Wy,cin,cout", [(2, 28, 28, 64, 128), (3, 7, 7, 256, 512), (1, 5, 9, 64, 64)])
 @pytest.mark.parametrize("with_res", [False, True])
 def test_conv_dgrad_stride2_by_parity(dev, B, Hy, Wy, cin, cout, with_res):

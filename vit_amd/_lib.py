@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 24
+ABI_VERSION = 25
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -101,6 +101,8 @@ SIGNATURES = {
     "rvit_bn_apply_pool": ([P, P, P, P, P, P, P, I, I, I, I, F, F, P, P, P], c_int),
     "rvit_bn_bwd_reduce": ([P, P, P, P, L, I, F, I, P, P, P], c_int),
     "rvit_bn_bwd_apply": ([P, P, P, P, P, P, P, P, P, P, L, I, F, I, P], c_int),
+    "rvit_bn_bwd_reduce_pool": ([P, P, P, P, P, I, I, I, I, F, P, P, P], c_int),
+    "rvit_bn_bwd_apply_pool": ([P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P], c_int),
     "rvit_maxpool3x3s2_bwd_nhwc": ([P, P, P, I, I, I, I, P], c_int),
 }
 

@@ -35,6 +35,20 @@ int rvit_bn_bwd_apply(const void* dz, const void* z, const void* y, const float*
                                 (hipStream_t)stream);
 }
 
+int rvit_bn_bwd_reduce_pool(const void* dpool, const void* argmax, const void* relu_mask, const void* y,
+                            const float* fwd_sums, int B, int H, int W, int C, float eps, float* bwd_sums, void* workspace,
+                            void* stream) {
+  return rvit_bn_bwd_reduce_pool_impl(dpool, argmax, relu_mask, y, fwd_sums, B, H, W, C, eps, bwd_sums, (float*)workspace,
+                                      (hipStream_t)stream);
+}
+
+int rvit_bn_bwd_apply_pool(const void* dpool, const void* argmax, const void* relu_mask, const void* y,
+                           const float* fwd_sums, const float* bwd_sums, const float* gamma, void* dy, float* dgamma,
+                           float* dbeta, int B, int H, int W, int C, float eps, void* stream) {
+  return rvit_bn_bwd_apply_pool_impl(dpool, argmax, relu_mask, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, B, H, W, C,
+                                     eps, (hipStream_t)stream);
+}
+
 int rvit_maxpool3x3s2_bwd_nhwc(const void* dpool, const void* argmax, void* dx, int B, int H, int W, int C,
                                void* stream) {
   return rvit_maxpool_bwd_impl(dpool, argmax, dx, B, H, W, C, (hipStream_t)stream);

@@ -367,12 +367,62 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const bf16* __restri
   *reinterpret_cast<uint2*>(argmax + obase) = a;
 }
 
+// POOL variants of the two backward kernels (the stem's first BatchNorm, whose ReLU output feeds the 3x3 / stride-2
+// max-pool): dz is not read from a map that rvit_maxpool3x3s2_bwd wrote but gathered here from the POOLED map's gradient
+// and the recorded argmax taps - the 2 x 411 MB round trip of that map at B = 256 and the launch disappear.  The value
+// is the one maxpool_bwd_kernel would have stored: the same fp32 sum over the (<= 4) windows in (kh, kw) order, rounded
+// to bf16.  Branch-free: the candidates that do not exist read candidate A again with a tap that matches nothing.
+struct PoolGeom {
+  const uint8_t* argmax;
+  int H, W, Ho, Wo;
+  float r_hw, r_w;   // 1 / (H * W), 1 / W: row index -> (b, hi, wi) by float-reciprocal division + fix-up (M < 2^24)
+};
+__device__ __forceinline__ void pool_grad8(const bf16* __restrict__ dpool, const PoolGeom& g, long m, int C, int c0,
+                                           float (&d)[8]) {
+  const int hw = g.H * g.W, mi = (int)m;
+  int b = (int)((float)mi * g.r_hw);
+  int rem = mi - b * hw;
+  if (rem < 0) { --b; rem += hw; } else if (rem >= hw) { ++b; rem -= hw; }
+  int hi = (int)((float)rem * g.r_w);
+  int wi = rem - hi * g.W;
+  if (wi < 0) { --hi; wi += g.W; } else if (wi >= g.W) { ++hi; wi -= g.W; }
+  // windows that contain row hi: ho = hi >> 1 with tap row 1 (even) or 2 (odd); odd rows also ho + 1 with tap row 0
+  const int hoA = hi >> 1, woA = wi >> 1;
+  const bool hB = (hi & 1) && hoA + 1 < g.Ho, wB = (wi & 1) && woA + 1 < g.Wo;
+  const int ho_[2] = {hB ? hoA + 1 : hoA, hoA}, wo_[2] = {wB ? woA + 1 : woA, woA};
+  const int kh_[2] = {hB ? 0 : 64, 1 + (hi & 1)}, kw_[2] = {wB ? 0 : 64, 1 + (wi & 1)};
+  uint4 dv[4];
+  uint2 am[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {   // (kh, kw) ascending: the order maxpool_bwd_kernel adds in
+    const long o = ((((long)b * g.Ho + ho_[q >> 1]) * g.Wo + wo_[q & 1]) * C) + c0;
+    dv[q] = *reinterpret_cast<const uint4*>(dpool + o);
+    am[q] = *reinterpret_cast<const uint2*>(g.argmax + o);
+  }
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tap = kh_[q >> 1] * 3 + kw_[q & 1];   // >= 64 for a candidate that does not exist: no byte matches
+    float v[8];
+    unpack8(dv[q], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int a = (int)(((k < 4 ? am[q].x : am[q].y) >> (8 * (k & 3))) & 0xff);
+      if (a == tap) acc[k] += v[k];
+    }
+  }
+  unpack8(pack8(acc), d);   // the bf16 rounding of the stored map
+}
+
+template <bool POOL>
 __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* __restrict__ dz,
                                                                     const bf16* __restrict__ z,
                                                                     const bf16* __restrict__ y,
                                                                     const float* __restrict__ fsums, long M, int C,
                                                                     float eps, int relu, float* __restrict__ bsums,
-                                                                    float* __restrict__ ws) {
+                                                                    float* __restrict__ ws, const PoolGeom pg) {
   extern __shared__ float red[];  // [2*C]; ordered form: [slots][2*C]
   if (!ws) {
     for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) red[i] = 0.f;
@@ -394,10 +444,12 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
   for (; m + step < s.m1; m += 2 * step) {
     uint4 du[2], yu[2], zu[2];
     unsigned mu[2];
+    float dq[2][8];   // POOL: the gathered gradient rows
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const long o = (m + j * step) * C + c0;
-      du[j] = *reinterpret_cast<const uint4*>(dz + o);
+      if constexpr (POOL) pool_grad8(dz, pg, m + j * step, C, c0, dq[j]);
+      else du[j] = *reinterpret_cast<const uint4*>(dz + o);
       yu[j] = *reinterpret_cast<const uint4*>(y + o);
       if (relu == 1) zu[j] = *reinterpret_cast<const uint4*>(z + o);
       if (relu == 2) mu[j] = zmask[(m + j * step) * cpr + s.chunk];
@@ -405,7 +457,12 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       float d[8], yv[8];
-      unpack8(du[j], d);
+      if constexpr (POOL) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = dq[j][k];
+      } else {
+        unpack8(du[j], d);
+      }
       unpack8(yu[j], yv);
       if (relu == 1) {
         float zv[8];
@@ -421,7 +478,8 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
   for (; m < s.m1; m += step) {
     const long o = m * C + c0;
     float d[8], yv[8];
-    unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
+    if constexpr (POOL) pool_grad8(dz, pg, m, C, c0, d);
+    else unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
     unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
     if (relu == 1) {
       float zv[8];
@@ -447,13 +505,14 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_kernel(const bf16* 
   for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) atomicAdd(bsums + i, red[i]);
 }
 
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ z,
                                                            const bf16* __restrict__ y, const float* __restrict__ fsums,
                                                            const float* __restrict__ bsums,
                                                            const float* __restrict__ gamma, bf16* __restrict__ dy,
                                                            bf16* __restrict__ dzm_out, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, long M, int C, float eps,
-                                                           int relu) {
+                                                           int relu, const PoolGeom pg) {
   const RowSpan s = row_span(M, C);
   const long step = s.rows_per_pass;
   const int c0 = s.chunk * 8, cpr = C >> 3;
@@ -480,10 +539,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
   for (; m + step < s.m1; m += 2 * step) {
     uint4 du[2], yu[2], zu[2];
     unsigned mu[2];
+    float dq[2][8];   // POOL: the gathered gradient rows
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const long o = (m + j * step) * C + c0;
-      du[j] = *reinterpret_cast<const uint4*>(dz + o);
+      if constexpr (POOL) pool_grad8(dz, pg, m + j * step, C, c0, dq[j]);
+      else du[j] = *reinterpret_cast<const uint4*>(dz + o);
       yu[j] = *reinterpret_cast<const uint4*>(y + o);
       if (relu == 1) zu[j] = *reinterpret_cast<const uint4*>(z + o);
       if (relu == 2) mu[j] = zmask[(m + j * step) * cpr + s.chunk];
@@ -492,7 +553,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
     for (int j = 0; j < 2; ++j) {
       const long o = (m + j * step) * C + c0;
       float d[8], yv[8], out[8];
-      unpack8(du[j], d);
+      if constexpr (POOL) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = dq[j][k];
+      } else {
+        unpack8(du[j], d);
+      }
       unpack8(yu[j], yv);
       if (relu == 1) {
         float zv[8];
@@ -510,7 +576,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
   for (; m < s.m1; m += step) {
     const long o = m * C + c0;
     float d[8], yv[8], out[8];
-    unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
+    if constexpr (POOL) pool_grad8(dz, pg, m, C, c0, d);
+    else unpack8(*reinterpret_cast<const uint4*>(dz + o), d);
     unpack8(*reinterpret_cast<const uint4*>(y + o), yv);
     if (relu == 1) {
       float zv[8];
@@ -640,8 +707,8 @@ int rvit_bn_bwd_reduce_impl(const void* dz, const void* z, const void* y, const 
   RVIT_CHECK_ARG(relu >= 0 && relu <= 2, "bn_bwd_reduce: relu is 0, 1 (z = forward output) or 2 (z = sign bits)");
   RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && (relu != 1 || rvit_aligned16(z)), "bn_bwd_reduce: alignment");
   const long blocks = red_blocks(M, C, ws != nullptr);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), red_lds(C, ws != nullptr), st,
-                     (const bf16*)dz, (const bf16*)z, (const bf16*)y, fsums, M, C, eps, relu, bsums, ws);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3((unsigned)blocks), dim3(RED_THREADS), red_lds(C, ws != nullptr), st,
+                     (const bf16*)dz, (const bf16*)z, (const bf16*)y, fsums, M, C, eps, relu, bsums, ws, PoolGeom{});
   RVIT_CHECK_LAUNCH("bn_bwd_reduce");
   return RVIT_OK;
 }
@@ -656,10 +723,54 @@ int rvit_bn_bwd_apply_impl(const void* dz, const void* z, const void* y, const f
                      (!dzm_out || rvit_aligned16(dzm_out)),
                  "bn_bwd_apply: alignment");
   const long blocks = bn_blocks(M, C, 8);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dz,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dz,
                      (const bf16*)z, (const bf16*)y, fsums, bsums, gamma, (bf16*)dy, (bf16*)dzm_out, dgamma, dbeta, M,
-                     C, eps, relu);
+                     C, eps, relu, PoolGeom{});
   RVIT_CHECK_LAUNCH("bn_bwd_apply");
+  return RVIT_OK;
+}
+
+// BatchNorm backward behind a 3x3 / stride-2 max-pool (the stem's bn1 -> relu -> maxpool, train_vit.py:145 through timm's
+// resnet): rvit_maxpool3x3s2_bwd_nhwc + rvit_bn_bwd_reduce / rvit_bn_bwd_apply (relu = 2) without the un-pooled gradient map
+static int pool_geom(const void* argmax, int B, int H, int W, int C, PoolGeom* g, const char* what) {
+  RVIT_CHECK_ARG(B > 0 && H > 1 && W > 1 && (long)B * H * W < (1L << 24), "%s: B*H*W must be below 2^24", what);
+  RVIT_CHECK_ARG(argmax && (((uintptr_t)argmax) & 7) == 0, "%s: argmax alignment", what);
+  g->argmax = (const uint8_t*)argmax;
+  g->H = H; g->W = W; g->Ho = (H - 1) / 2 + 1; g->Wo = (W - 1) / 2 + 1;
+  g->r_hw = 1.0f / (float)(H * W); g->r_w = 1.0f / (float)W;
+  (void)C;
+  return RVIT_OK;
+}
+
+int rvit_bn_bwd_reduce_pool_impl(const void* dpool, const void* argmax, const void* relu_mask, const void* y,
+                                 const float* fsums, int B, int H, int W, int C, float eps, float* bsums, float* ws,
+                                 hipStream_t st) {
+  const long M = (long)B * H * W;
+  RVIT_CHECK_ARG(dpool && relu_mask && y && fsums && bsums && bn_shape_ok(M, C), "bn_bwd_reduce_pool: bad arguments");
+  RVIT_CHECK_ARG(rvit_aligned16(dpool) && rvit_aligned16(y), "bn_bwd_reduce_pool: alignment");
+  PoolGeom g;
+  if (const int rc = pool_geom(argmax, B, H, W, C, &g, "bn_bwd_reduce_pool")) return rc;
+  const long blocks = red_blocks(M, C, ws != nullptr);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3((unsigned)blocks), dim3(RED_THREADS), red_lds(C, ws != nullptr), st,
+                     (const bf16*)dpool, (const bf16*)relu_mask, (const bf16*)y, fsums, M, C, eps, 2, bsums, ws, g);
+  RVIT_CHECK_LAUNCH("bn_bwd_reduce_pool");
+  return RVIT_OK;
+}
+
+int rvit_bn_bwd_apply_pool_impl(const void* dpool, const void* argmax, const void* relu_mask, const void* y,
+                                const float* fsums, const float* bsums, const float* gamma, void* dy, float* dgamma,
+                                float* dbeta, int B, int H, int W, int C, float eps, hipStream_t st) {
+  const long M = (long)B * H * W;
+  RVIT_CHECK_ARG(dpool && relu_mask && y && fsums && bsums && gamma && dy && dgamma && dbeta && bn_shape_ok(M, C),
+                 "bn_bwd_apply_pool: bad arguments");
+  RVIT_CHECK_ARG(rvit_aligned16(dpool) && rvit_aligned16(y) && rvit_aligned16(dy), "bn_bwd_apply_pool: alignment");
+  PoolGeom g;
+  if (const int rc = pool_geom(argmax, B, H, W, C, &g, "bn_bwd_apply_pool")) return rc;
+  const long blocks = bn_blocks(M, C, 8);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dpool,
+                     (const bf16*)relu_mask, (const bf16*)y, fsums, bsums, gamma, (bf16*)dy, (bf16*)nullptr, dgamma, dbeta,
+                     M, C, eps, 2, g);
+  RVIT_CHECK_LAUNCH("bn_bwd_apply_pool");
   return RVIT_OK;
 }
 

@@ -230,4 +230,10 @@ int rvit_bn_bwd_reduce_impl(const void* dz, const void* z, const void* y, const 
 int rvit_bn_bwd_apply_impl(const void* dz, const void* z, const void* y, const float* fsums, const float* bsums,
                            const float* gamma, void* dy, void* dzm_out, float* dgamma, float* dbeta, long M, int C,
                            float eps, int relu, hipStream_t st);
+int rvit_bn_bwd_reduce_pool_impl(const void* dpool, const void* argmax, const void* relu_mask, const void* y,
+                                 const float* fsums, int B, int H, int W, int C, float eps, float* bsums, float* ws,
+                                 hipStream_t st);
+int rvit_bn_bwd_apply_pool_impl(const void* dpool, const void* argmax, const void* relu_mask, const void* y,
+                                const float* fsums, const float* bsums, const float* gamma, void* dy, float* dgamma,
+                                float* dbeta, int B, int H, int W, int C, float eps, hipStream_t st);
 int rvit_maxpool_bwd_impl(const void* dpool, const void* argmax, void* dx, int B, int H, int W, int C, hipStream_t st);

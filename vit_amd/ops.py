@@ -1303,6 +1303,39 @@ def bn_bwd(dz: torch.Tensor, z: Optional[torch.Tensor], y: torch.Tensor, fwd_sum
     return dy
 
 
+def bn_bwd_pool(dpool: torch.Tensor, argmax: torch.Tensor, relu_mask: torch.Tensor, y: torch.Tensor,
+                fwd_sums: torch.Tensor, bwd_sums: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor,
+                dgamma: torch.Tensor, dbeta: torch.Tensor, *, eps: float,
+                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """maxpool3x3s2_bwd + bn_bwd(relu=True, relu_mask=...) in two launches instead of three: the un-pooled gradient
+    map is gathered inside the two BatchNorm passes instead of being written and read twice (same bits).
+    dpool / argmax [B,Ho,Wo,C], y / dy [B,H,W,C], relu_mask the bits bn_apply_pool wrote; bwd_sums zero on entry."""
+    _need_cuda(dpool, argmax, relu_mask, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, workspace)
+    _check_bn_ws(workspace)
+    if y.dim() != 4:
+        raise ValueError("bn_bwd_pool: y must be [B,H,W,C]")
+    B, H, W, C = y.shape
+    M = B * H * W
+    _check_relu_mask(relu_mask, M, C, True)
+    if dpool.shape != argmax.shape or tuple(dpool.shape) != (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C) \
+            or dpool.dtype != BF16 or y.dtype != BF16 or dy.dtype != BF16 or argmax.dtype != torch.uint8 \
+            or dy.shape != y.shape or not all(t.is_contiguous() for t in (dpool, argmax, y, dy)) or M >= 1 << 24:
+        raise ValueError("bn_bwd_pool: bad operands")
+    for v, n in ((fwd_sums, 2 * C), (bwd_sums, 2 * C), (gamma, C), (dgamma, C), (dbeta, C)):
+        _vec_f32(v, n, "bn_bwd_pool: vector")
+    lib = _lib.load()
+    with _Span("bn_bwd_reduce", 0, _nbytes(dpool, argmax, y, relu_mask)):
+        check(lib.rvit_bn_bwd_reduce_pool(dpool.data_ptr(), argmax.data_ptr(), relu_mask.data_ptr(), y.data_ptr(),
+                                          fwd_sums.data_ptr(), B, H, W, C, eps, bwd_sums.data_ptr(), _ptr(workspace),
+                                          _stream()), "rvit_bn_bwd_reduce_pool")
+    with _Span("bn_bwd_apply", 0, _nbytes(dpool, argmax, y, relu_mask, dy)):
+        check(lib.rvit_bn_bwd_apply_pool(dpool.data_ptr(), argmax.data_ptr(), relu_mask.data_ptr(), y.data_ptr(),
+                                         fwd_sums.data_ptr(), bwd_sums.data_ptr(), gamma.data_ptr(), dy.data_ptr(),
+                                         dgamma.data_ptr(), dbeta.data_ptr(), B, H, W, C, eps, _stream()),
+              "rvit_bn_bwd_apply_pool")
+    return dy
+
+
 def maxpool3x3s2_bwd(dpool: torch.Tensor, argmax: torch.Tensor, dx: torch.Tensor) -> torch.Tensor:
     _need_cuda(dpool, argmax, dx)
     B, H, W, C = dx.shape

@@ -247,6 +247,8 @@ class TrainEngine:
         # scratch workspace per device).  With both on, two runs of a step give the same bits in every gradient and
         # parameter.  RVIT_ORDERED=0 selects the float-atomic forms.
         self.ordered = os.environ.get("RVIT_ORDERED", "1") != "0"
+        # stem bn1 backward with the max-pool gradient gathered in its two passes (0: maxpool_bwd + bn_bwd, for A/B runs)
+        self.fused_pool_bwd = os.environ.get("RVIT_POOL_BWD_FUSED", "1") != "0"
         self.mb = None   # MobileStemTrainer for backbone='mobilenetv3'
         if getattr(model, "backbone_name", None) == "mobilenetv3":
             from .mobile_trainer import MobileStemTrainer
@@ -594,12 +596,18 @@ class TrainEngine:
             # layout order inside a block is the reverse of module order: conv1.weight closes the block
             self._maybe_reduce(flat, pref + "conv1.weight")
         # max-pool and the 7x7 stem conv (its input is the image: no dgrad)
-        dc1 = self._scratch(b, ("dc1",), b["c1_y"])
-        ops.maxpool3x3s2_bwd(dz, b["pool_arg"], dc1)
         dyc = self._scratch(b, ("dyc",), b["c1_y"])
-        ops.bn_bwd(dc1, None, b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(), dyc,
-                   self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"), eps=cb.bn1.eps,
-                   relu=True, relu_mask=b["c1_m"], workspace=ws)
+        if self.fused_pool_bwd:
+            # the max-pool's gradient is gathered inside the two BatchNorm passes: no un-pooled gradient map (same bits)
+            ops.bn_bwd_pool(dz, b["pool_arg"], b["c1_m"], b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(),
+                            dyc, self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"),
+                            eps=cb.bn1.eps, workspace=ws)
+        else:
+            dc1 = self._scratch(b, ("dc1",), b["c1_y"])
+            ops.maxpool3x3s2_bwd(dz, b["pool_arg"], dc1)
+            ops.bn_bwd(dc1, None, b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(), dyc,
+                       self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"), eps=cb.bn1.eps,
+                       relu=True, relu_mask=b["c1_m"], workspace=ws)
         dw1 = torch.zeros(64, 224, dtype=F32, device=dyc.device)
         ops.conv2d_wgrad(dyc, b["img"], dw1, kh=7, kw=1, stride=2, pad=0, seg_len=32)
         self._g(flat, "cnn_backbone.conv1.weight").view(64, 7, 7, 3).copy_(dw1.view(64, 7, 8, 4)[:, :, :7, :3])
