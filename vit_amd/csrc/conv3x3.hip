@@ -457,7 +457,10 @@ int rvit_conv3x3_auto(const GemmArgs& a) {
   if (rvit_conv3x3_p8_pays(a)) return RVIT_CONV_P8;
   const int P = c3_patch_pixels(a.H, a.W);
   const int patch_bytes = ((P + 7) / 8) * 1024;
-  if ((a.N & 255) == 0 && patch_bytes + 2 * 256 * 128 <= 160 * 1024 && a.Cpix >= 512) return RVIT_CONV_C256;
+  const int tr = c3_tile_rows(a.H, a.W);
+  const int tile_len = tr > 0 ? tr * a.W : C3_BM;
+  const long tiles256 = ((a.M + tile_len - 1) / tile_len) * (long)(a.N / 256);
+  if ((a.N & 255) == 0 && patch_bytes + 2 * 256 * 128 <= 160 * 1024 && a.Cpix >= 512 && tiles256 >= 160) return RVIT_CONV_C256;
   return RVIT_CONV_DIRECT;
 }
 
@@ -501,7 +504,11 @@ int rvit_conv3x3_direct(const GemmArgs& a, int variant, hipStream_t st) {
   // channels (a property of the layer, never of the batch size), tile 15 forces it.
   const bool c256_ok = (a.N & 255) == 0 && patch_bytes + 2 * 256 * 128 <= 160 * 1024;
   if (variant == 5) RVIT_CHECK_ARG(c256_ok, "conv3x3: the 256-channel variant does not fit this geometry");
-  if (variant == 5 || (variant == 0 && c256_ok && a.Cpix >= 512)) {
+  // One workgroup per CU and tiles of 256 pixels x 256 channels: a launch of fewer than ~160 such tiles leaves the chip
+  // part empty for the same ~102 us (layer4: B = 256 102 us against 63 us for the 64-channel tiles, B = 384 105 / 101,
+  // B = 512 106 / 126; profiles/r03_session2_notes.txt #9).  The choice by batch is safe: same bits.
+  const long tiles256 = ((a.M + tile_len - 1) / tile_len) * (long)(a.N / 256);
+  if (variant == 5 || (variant == 0 && c256_ok && a.Cpix >= 512 && tiles256 >= 160)) {
     // a third ring stage where it fits (layer4: 53 + 96 KB): -2 % (108.6 -> 106.1 us at B = 512), same bits
     if (patch_bytes + 3 * 256 * 128 <= 160 * 1024) return c3_launch<256, false, 16, 3>(a, patch_bytes, tile_len, st);
     return c3_launch<256, false, 16>(a, patch_bytes, tile_len, st);
