@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 25
+#define RVIT_ABI_VERSION 26
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -420,6 +420,18 @@ int rvit_attn_fwd_mx(const void* qkv, uint8_t* out_q, int64_t ldo, uint8_t* out_
 int rvit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int S,
                   int H, int64_t ldq, int64_t ldo, int64_t lddo, int64_t lddq, float scale, float drop_p,
                   uint64_t drop_seed, void* stream);
+
+/* The classifier tail in one launch (train_vit.py:127-131, 166-185: `x = self.norm(x[:, 0]); return self.head(x)` with
+ * head = Linear(E, E/2) -> GELU -> Dropout -> Linear(E/2, classes), eval mode):
+ *   logits[b] = w3 . gelu(w0 . LayerNorm(x[b]) + b0) + b3
+ * x: fp32 rows of pitch ldx (the class-token rows of the token stream: ldx = S*E), w0 bf16 [hidden, E], w3 bf16
+ * [num_classes, hidden], logits fp32 [B, ldl].  The same bits as rvit_layernorm_fwd (bf16 out) -> rvit_gemm_bf16 (bias,
+ * GELU, bf16 out) -> rvit_gemm_bf16 (bias, fp32 out).  E and hidden multiples of 32 up to 1024
+ * (rvit_cls_head_supported says so; other shapes keep the three calls). */
+int rvit_cls_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w0,
+                      const float* b0, const void* w3, const float* b3, float* logits, int64_t ldl, int B, int E,
+                      int hidden, int num_classes, void* stream);
+int rvit_cls_head_supported(int E, int hidden, int num_classes);
 
 /* rvit_attn_fwd / rvit_attn_bwd for the other head dims the reference's constructor accepts (train_vit.py:76-111 builds
  * nn.TransformerEncoderLayer(d_model=embed_dim, nhead=num_heads) for any embed_dim % num_heads == 0; torch

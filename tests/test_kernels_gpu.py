@@ -319,6 +319,35 @@ def test_conv_128x128_tile_bit_identical(dev, cin, cout, hw, k):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("B,S,E,C", [(512, 50, 256, 11), (33, 197, 768, 11), (1, 50, 256, 11), (17, 197, 1024, 11),
+                                     (5, 50, 128, 3), (40, 50, 192, 37), (16, 50, 384, 16)])
+def test_cls_head_fused(dev, B, S, E, C):
+    """Final LayerNorm of the class-token rows + Linear / GELU / Linear in one launch (csrc/head.hip) against the three
+    launches it replaces: the same bits, for every width the engine sends to it; and against torch fp32."""
+    from vit_amd import ops
+    H = E // 2
+    assert ops.cls_head_supported(E, H, C)
+    g = torch.Generator().manual_seed(B + E + C)
+    xs = (torch.randn(B, S * E, generator=g) * 1.7 + 0.3).to(dev)
+    rows = xs[:, :E]                      # row pitch S * E, as the engine's token stream
+    gam, bet = (torch.rand(E, generator=g) + 0.5).to(dev), (torch.randn(E, generator=g) * 0.2).to(dev)
+    w0 = _bf(torch.randn(H, E, generator=g) / math.sqrt(E)).to(dev)
+    w3 = _bf(torch.randn(C, H, generator=g) / math.sqrt(H)).to(dev)
+    b0, b3 = torch.randn(H, generator=g).to(dev) * 0.1, torch.randn(C, generator=g).to(dev) * 0.1
+    ln = torch.empty(B, E, dtype=torch.bfloat16, device=dev)
+    h0 = torch.empty(B, H, dtype=torch.bfloat16, device=dev)
+    want = torch.empty(B, C, device=dev)
+    ops.layernorm(rows, gam, bet, ln, 1e-5)
+    ops.gemm(ln, w0, h0, bias=b0, act="gelu")
+    ops.gemm(h0, w3, want, bias=b3)
+    got = torch.full((B, C), float("nan"), device=dev)
+    ops.cls_head(rows, gam, bet, 1e-5, w0, b0, w3, b3, got)
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    ref = F.gelu(F.layer_norm(rows.cpu(), (E,), gam.cpu(), bet.cpu(), 1e-5) @ w0.float().cpu().T + b0.cpu()) @ w3.float().cpu().T \
+        + b3.cpu()
+    _close(got, ref, 2e-2, 2e-2, "cls_head vs torch")
+
+
 def _conv_ref(x_nhwc, w_ohwi, stride, pad):
     return F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w_ohwi.float().permute(0, 3, 1, 2), None, stride, pad)
 

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 25
+ABI_VERSION = 26
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -61,6 +61,8 @@ SIGNATURES = {
     "rvit_layernorm_bwd": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P, L, P], c_int),
     "rvit_layernorm_bwd_drop": ([P, L, P, L, P, P, P, P, L, I, P, L, P, P, L, I, P, L, F, U64, P], c_int),
     "rvit_attn_fwd": ([P, P, P, I, I, I, L, L, F, F, U64, P], c_int),
+    "rvit_cls_head_fwd": ([P, L, P, P, F, P, P, P, P, P, L, I, I, I, I, P], c_int),
+    "rvit_cls_head_supported": ([I, I, I], c_int),
     "rvit_attn_dh_fwd": ([P, P, P, I, I, I, I, L, L, F, F, U64, P], c_int),
     "rvit_attn_dh_bwd": ([P, P, P, P, P, I, I, I, I, L, L, L, L, F, F, U64, P], c_int),
     "rvit_attn_fwd_fp8": ([P, P, L, P, I, I, I, L, F, P], c_int),

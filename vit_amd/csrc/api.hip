@@ -447,6 +447,15 @@ int rvit_attn_bwd(const void* qkv, const void* out, const void* dout, const floa
                             (hipStream_t)stream);
 }
 
+int rvit_cls_head_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const void* w0,
+                      const float* b0, const void* w3, const float* b3, float* logits, int64_t ldl, int B, int E,
+                      int hidden, int num_classes, void* stream) {
+  return rvit_cls_head_fwd_impl(x, ldx, gamma, beta, eps, w0, b0, w3, b3, logits, ldl, B, E, hidden, num_classes,
+                                (hipStream_t)stream);
+}
+
+int rvit_cls_head_supported(int E, int hidden, int num_classes) { return rvit_cls_head_ok(E, hidden, num_classes) ? 1 : 0; }
+
 int rvit_attn_dh_fwd(const void* qkv, void* out, float* lse, int B, int S, int H, int head_dim, int64_t ldq, int64_t ldo,
                      float scale, float drop_p, uint64_t drop_seed, void* stream) {
   return rvit_attn_dh_fwd_impl(qkv, out, lse, B, S, H, head_dim, ldq, ldo, scale, drop_p, drop_seed, (hipStream_t)stream);

@@ -201,6 +201,10 @@ int rvit_attn_dh_fwd_impl(const void* qkv, void* out, float* lse, int B, int S, 
 int rvit_attn_dh_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
                           int Dh, long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,
                           hipStream_t st);
+bool rvit_cls_head_ok(int E, int HID, int C);   // head.hip
+int rvit_cls_head_fwd_impl(const float* x, long ldx, const float* gamma, const float* beta, float eps, const void* w0,
+                           const float* b0, const void* w3, const float* b3, float* logits, long ldl, int B, int E, int HID,
+                           int C, hipStream_t st);
 int rvit_attn16_impl(const void* qkv, void* out, int B, int S, int H, long ldq, long ldo, float scale, hipStream_t st);
 int rvit_attn_bwd_impl(const void* qkv, const void* O, const void* dO, const float* lse, void* dqkv, int B, int S, int H,
                        long ldq, long ldo, long lddo, long lddq, float scale, float drop_p, uint64_t drop_seed,

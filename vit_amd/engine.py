@@ -62,6 +62,7 @@ class Engine:
         self.fused_encoder = os.environ.get("RVIT_ENCODER_FUSED", "1") != "0"
         self.FUSED_MIN_TOKENS = int(os.environ.get("RVIT_FUSED_MIN_TOKENS", "12800"))
         self.fused_stack = os.environ.get("RVIT_ENCODER_STACK", "1") != "0"   # all layers in one launch (A/B: 0 = per layer)
+        self.fused_head = os.environ.get("RVIT_FUSED_HEAD", "1") != "0"        # norm + head in one launch (A/B: 0 = three)
         self.graph_max_batch = 0
 
     def set_precision(self, precision: str, fp8_attention=None) -> None:
@@ -411,9 +412,13 @@ class Engine:
             out = torch.empty(B, E, dtype=torch.float32, device=x.device)
             ops.layernorm(cls_rows, P["norm_w"], P["norm_b"], out, m.norm.eps)
             return out
+        logits = torch.empty(B, m.num_classes, dtype=torch.float32, device=x.device)
+        if self.fused_head and ops.cls_head_supported(E, P["h0_w"].shape[0], m.num_classes):
+            # final LayerNorm + both Linears of the head in one launch (csrc/head.hip; same bits as the three below)
+            return ops.cls_head(cls_rows, P["norm_w"], P["norm_b"], m.norm.eps, P["h0_w"], P["h0_b"], P["h3_w"], P["h3_b"],
+                                logits)
         ops.layernorm(cls_rows, P["norm_w"], P["norm_b"], b["cls_ln"], m.norm.eps)
         ops.gemm(b["cls_ln"], P["h0_w"], b["h0"], bias=P["h0_b"], act="gelu")
-        logits = torch.empty(B, m.num_classes, dtype=torch.float32, device=x.device)
         ops.gemm(b["h0"], P["h3_w"], logits, bias=P["h3_b"])
         return logits
 

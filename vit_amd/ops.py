@@ -540,6 +540,30 @@ def layernorm_mx(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, q: to
     return q, scales
 
 
+def cls_head_supported(E: int, hidden: int, num_classes: int) -> bool:
+    return bool(_lib.load().rvit_cls_head_supported(int(E), int(hidden), int(num_classes)))
+
+
+def cls_head(x_rows: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w0: torch.Tensor, b0: torch.Tensor,
+             w3: torch.Tensor, b3: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+    """logits = w3 . gelu(w0 . LayerNorm(x_rows) + b0) + b3 in one launch (the bits of layernorm -> gemm(gelu) -> gemm):
+    x_rows fp32 [B, E] (any row pitch), w0 bf16 [hidden, E], w3 bf16 [classes, hidden], logits fp32 [B, classes]."""
+    _need_cuda(x_rows, gamma, beta, w0, b0, w3, b3, logits)
+    B, E, ldx = _rows2d(x_rows, "cls_head x")
+    hidden, C = w0.shape[0], w3.shape[0]
+    if x_rows.dtype != torch.float32 or logits.dtype != torch.float32 or w0.dtype != BF16 or w3.dtype != BF16 \
+            or w0.shape != (hidden, E) or w3.shape != (C, hidden) or logits.shape != (B, C) or logits.stride(1) != 1 \
+            or not (w0.is_contiguous() and w3.is_contiguous()):
+        raise ValueError("cls_head: shape / dtype mismatch")
+    for v, n in ((gamma, E), (beta, E), (b0, hidden), (b3, C)):
+        _vec_f32(v, n, "cls_head: vector")
+    with _Span("cls_head", 2 * B * hidden * (E + C), _nbytes(x_rows, w0, w3, logits)):
+        check(_lib.load().rvit_cls_head_fwd(x_rows.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                            w0.data_ptr(), b0.data_ptr(), w3.data_ptr(), b3.data_ptr(), logits.data_ptr(),
+                                            logits.stride(0), B, E, hidden, C, _stream()), "rvit_cls_head_fwd")
+    return logits
+
+
 ATTN_HEAD_DIMS = (16, 32, 48, 64, 96, 128)
 
 
