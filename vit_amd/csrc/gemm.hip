@@ -406,6 +406,10 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   else if (a.mode == 0 && a.K >= 512 && t256 >= 512 && rvit_gemm8p_ok(a)) cfg = 5;   // eight waves, four-phase K tile (gemm8p.hip): 0.92-1.13 vs 0.59-0.90 PFLOP/s on the ViT-B Linears, same bits
   else if (big) cfg = 4;
   else if (mid_conv) cfg = 7;
+  // plain products below the eight-wave kernel's range with N a multiple of 128 (the E = 256 encoder's Linears at a
+  // training batch: 12,800 x {256, 768, 1024} x {256, 768, 1024}): 128x128 on eight waves, two workgroups per CU,
+  // 5-10 % ahead of the 64-column tiles (scripts/bench_gemm_small.py: 17.1 -> 15.4, 23.6 -> 21.8, 15.9 -> 14.5 us)
+  else if (a.mode == 0 && (a.N & 127) == 0 && ((a.M + 127) / 128) * (long)(a.N / 128) >= 192) cfg = 7;
   else if (((a.M + 255) / 256) * n64 >= 384) cfg = 1;
   else if (((a.M + 127) / 128) * n64 >= 256) cfg = 2;
   else cfg = 3;
