@@ -400,7 +400,7 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
   // B=512 layer2.0.conv1 147 -> 118 us, the three downsample convs 47 / 31 / 23 -> 45 / 29 / 21 us; 256x128 on sixteen
   // waves 135 us (profiles/r03_session2_notes.txt #7).  Same K order, same bits.
   const bool mid_conv = a.mode == 1 && !a.transposed && !big_conv && (a.N & 127) == 0 &&
-                        ((a.M + 127) / 128) * (long)(a.N / 128) >= 512;
+                        ((a.M + 127) / 128) * (long)(a.N / 128) >= 192;
   int cfg;
   if (forced) cfg = forced;
   else if (a.mode == 0 && a.K >= 512 && t256 >= 512 && rvit_gemm8p_ok(a)) cfg = 5;   // eight waves, four-phase K tile (gemm8p.hip): 0.92-1.13 vs 0.59-0.90 PFLOP/s on the ViT-B Linears, same bits
