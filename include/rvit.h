@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 26
+#define RVIT_ABI_VERSION 27
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -137,6 +137,16 @@ int rvit_conv2d_fwd_stats_bf16(const void* x, const void* w, void* y, int B, int
                                int KW, int stride, int pad, int Ho, int Wo, int Cout, void* stat_ws, int64_t stat_ws_bytes,
                                int* stat_slots, int tile, void* stream);
 int rvit_bn_stats_finalize(const void* stat_ws, int stat_slots, int C, float* sums, void* stage, void* stream);
+
+/* The stem's first conv in a training step (timm resnet18 `conv1` 7x7 / stride 2 / pad 3, 3 -> 64, under
+ * train_vit.py:87,145 in train()): y bf16 [B,112,112,64] = conv(x) read straight from the fp32 NCHW input
+ * [B,3,224,224] (rounded to bf16 as rvit_input_pack_nhwc4 would), with the batch statistics of the stored map as
+ * rvit_conv2d_fwd_stats_bf16 gives them: *stat_slots slots of 128 floats (sum[64] | sum of squares[64]) in stat_ws, to be
+ * added by rvit_bn_stats_finalize(stat_ws, *stat_slots, 64, ...).  w: bf16 [64, 224], k = kh*32 + px*4 + ch (the layout
+ * rvit_conv2d_fwd_bf16 takes for this conv with seg_len 32).  Same products in the same kh order as that call on the
+ * packed image; one workgroup walks down an image (or a part of it), every input row is fetched once. */
+int rvit_stem_conv1_stats_f32_fwd(const float* x, const void* w, void* y, void* stat_ws, int64_t stat_ws_bytes,
+                                  int* stat_slots, int B, void* stream);
 
 /* Which kernel rvit_conv2d_fwd_bf16 / rvit_conv2d_dgrad_bf16 run (tile 0) for a 3x3 / stride 1 / pad 1 convolution of B
  * images of H x W x Cin -> Cout (16-byte aligned operands): 0 implicit-GEMM gather kernel, 1 generic direct kernel

@@ -348,6 +348,36 @@ def test_cls_head_fused(dev, B, S, E, C):
     _close(got, ref, 2e-2, 2e-2, "cls_head vs torch")
 
 
+@pytest.mark.parametrize("B", [3, 37, 130, 256, 600])
+def test_stem_conv1_training_form(dev, B):
+    """rvit_stem_conv1_stats_f32_fwd (round 3): the stem's 7x7 conv of a training step read from the fp32 NCHW input by
+    the rolling-band kernel, against input_pack + the implicit-GEMM conv: the stored map bit-identical (same products in
+    the same kh order), the statistics equal to rvit_bn_stats of the stored map up to fp32 summation order, two runs
+    identical (no atomics).  The batches cover every workgroups-per-image split (28 ... 1)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(B)
+    x = (torch.randn(B, 3, 224, 224, generator=g) * 1.5).to(dev)
+    w = _bf(torch.randn(64, 7 * 32, generator=g) / 12).to(dev)
+    img = torch.zeros(B, 230, 232, 4, dtype=torch.bfloat16, device=dev)
+    ops.input_pack(x, img, 3, 3)
+    y_ref = torch.empty(B, 112, 112, 64, dtype=torch.bfloat16, device=dev)
+    ops.conv2d(img, w, y_ref, kh=7, kw=1, stride=2, pad=0, seg_len=32)
+    want = torch.zeros(128, device=dev)
+    ops.bn_stats(y_ref, want, ops.bn_workspace(dev))
+    ws = ops.conv_stats_workspace(dev)
+    runs = []
+    for _ in range(2):
+        y = torch.full_like(y_ref, float("nan"))
+        sums = torch.zeros(128, device=dev)
+        ops.stem_conv1_stats_f32(x, w, y, sums, ws)
+        assert torch.equal(y, y_ref), (y.float() - y_ref.float()).abs().max().item()
+        runs.append(sums)
+    assert torch.equal(runs[0], runs[1])
+    n = B * 112 * 112
+    assert torch.allclose(runs[0][:64] / n, want[:64] / n, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(runs[0][64:] / n, want[64:] / n, rtol=1e-4, atol=1e-5)
+
+
 def _conv_ref(x_nhwc, w_ohwi, stride, pad):
     return F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w_ohwi.float().permute(0, 3, 1, 2), None, stride, pad)
 

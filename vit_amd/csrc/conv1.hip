@@ -527,6 +527,173 @@ __global__ __launch_bounds__(512, 4) void conv1_pool_roll_kernel(const float* __
   C1R_FLUSH;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Training form of the rolling band (round 3): the raw conv rows go to HBM as bf16 [B,112,112,64] (train-mode BatchNorm
+// needs the batch statistics of the whole map before it can normalise a pixel) together with the per-channel sum and sum
+// of squares of the STORED values, one slot of 128 floats per workgroup (rvit_bn_stats_finalize adds the slots in order).
+// Replaces the implicit-GEMM launch of this conv (K = 224: four K steps per 256-pixel tile, 12,544 tiles at B = 256, all
+// prologue and epilogue: 289 us) and its 12,544 statistics slots.  Same ring, same fragments and the same kh order as the
+// kernel above; a wave owns conv columns 14w - 1 .. 14w + 14 and stores the fourteen in the middle.  No stagger of the
+// two wave groups here, and a band's four rows in two passes of two (the 32 statistics accumulators take the registers
+// the carried rows / the other two rows' accumulators would need at four waves per SIMD).
+__global__ __launch_bounds__(512, 4) void conv1_rows_roll_kernel(const float* __restrict__ xin, const bf16* __restrict__ w,
+                                                                 bf16* __restrict__ y, float* __restrict__ stat_part,
+                                                                 int wpi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sW = smem;
+  char* const sP = smem + W_BYTES;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x / wpi, seg = blockIdx.x - b * wpi;
+  const int nb = BANDS / wpi;
+  const int band0 = seg * nb;
+  const float* __restrict__ x = xin + (long)b * 3 * 224 * 224;
+
+  // weights [64][224] -> LDS rows of W_PITCH bytes (the pitch that keeps the fragment reads conflict-free)
+  for (int i = t; i < 64 * 28; i += 512) {
+    const int r = i / 28, c = i - r * 28;
+    *reinterpret_cast<uint4*>(sW + r * W_PITCH + c * 16) = *reinterpret_cast<const uint4*>(w + r * 224 + c * 8);
+  }
+  int c0 = 4 * band0;
+  {
+    const int p_first = 2 * c0;
+    constexpr int UPT = 2;                                       // 13 * 56 = 728 units of 4 pixels x 3 planes
+    float4 v[UPT][3];
+    int dst[UPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int id = t + u * 512;
+      const int r = id / 56, j = id - r * 56;
+      const int p = p_first + r, ir = p - 3;
+      dst[u] = -1;
+      if (r < 13 && (unsigned)ir < 224u) {
+        const float* src = x + (long)ir * 224 + 4 * j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[u][c] = *reinterpret_cast<const float4*>(src + (long)c * 224 * 224);
+        dst[u] = (p % RING_ROWS) * ROW_B + (4 * j + 3) * 8;
+      }
+    }
+    for (int i = t; i < RING_BYTES / 16; i += 512) *reinterpret_cast<uint4*>(sP + i * 16) = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      if (dst[u] < 0) continue;
+      const float p0[4] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w};
+      const float p1[4] = {v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+      const float p2[4] = {v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
+      uint2 px[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        px[e].x = pack_bf16x2(p0[e], p1[e]);
+        px[e].y = pack_bf16x2(p2[e], 0.f);
+      }
+      char* d = sP + dst[u];
+      *reinterpret_cast<uint2*>(d) = px[0];
+      *reinterpret_cast<uint4*>(d + 8) = uint4{px[1].x, px[1].y, px[2].x, px[2].y};
+      *reinterpret_cast<uint2*>(d + 24) = px[3];
+    }
+  }
+  __syncthreads();
+
+  const char* const sWl = sW + fr * W_PITCH + fq * 16;
+  const char* const sPl = sP + 16 * (14 * wave - 1 + fr + fq);
+  const bool store_ok = fr >= 1 && fr <= 14;
+  const int col = 14 * wave + fr - 1;
+  const int ch_off = (fq & 1) * 16 + (fq >> 1) * 8;
+  const int pf_r = t / 56, pf_j = t - pf_r * 56;
+  const bool pf_thread = t < 8 * 56;
+  const int pf_col = (4 * pf_j + 3) * 8;
+
+  float s1[16], s2[16];   // channels 16 j + 4 fq + 2 d + e at index 4 j + 2 d + e
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+
+#pragma unroll 1
+  for (int bi = 0; bi < nb; ++bi, c0 += 4) {
+    const bool has_next = bi + 1 < nb;
+    float4 nv[3];
+    nv[0] = nv[1] = nv[2] = float4{0.f, 0.f, 0.f, 0.f};
+    const int np = 2 * c0 + 13 + pf_r;
+    if (has_next && pf_thread && np - 3 < 224) {
+      const float* src = x + (long)(np - 3) * 224 + 4 * pf_j;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nv[c] = *reinterpret_cast<const float4*>(src + (long)c * 224 * 224);
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {   // two passes of two rows: 32 accumulator registers beside the 32 of the statistics
+      f32x4 acc[2][4];
+      c1_rows_mfma<2>(sWl, sPl, __builtin_amdgcn_readfirstlane((2 * c0 + 4 * half) % RING_ROWS), acc);
+      bf16* dst = y + (((long)b * WC + c0 + 2 * half) * WC + col) * 64 + ch_off;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          pk[2 * j] = pack_bf16x2(acc[q][j][0], acc[q][j][1]);
+          pk[2 * j + 1] = pack_bf16x2(acc[q][j][2], acc[q][j][3]);
+        }
+        if (store_ok) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float lo = bf16_lo(pk[k]), hi = bf16_hi(pk[k]);
+            s1[2 * k] += lo; s2[2 * k] = fmaf(lo, lo, s2[2 * k]);
+            s1[2 * k + 1] += hi; s2[2 * k + 1] = fmaf(hi, hi, s2[2 * k + 1]);
+          }
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {   // lane rows fq 0 <-> 1, 2 <-> 3: eight consecutive channels per lane
+          const auto w0 = __builtin_amdgcn_permlane16_swap(pk[4 * pr + 0], pk[4 * pr + 2], false, false);
+          const auto w1 = __builtin_amdgcn_permlane16_swap(pk[4 * pr + 1], pk[4 * pr + 3], false, false);
+          uint4 o;
+          o.x = w0[0]; o.y = w1[0]; o.z = w0[1]; o.w = w1[1];
+          if (store_ok) *reinterpret_cast<uint4*>(dst + (long)q * WC * 64 + 32 * pr) = o;
+        }
+      }
+    }
+    if (has_next && pf_thread) {
+      const float p0[4] = {nv[0].x, nv[0].y, nv[0].z, nv[0].w};
+      const float p1[4] = {nv[1].x, nv[1].y, nv[1].z, nv[1].w};
+      const float p2[4] = {nv[2].x, nv[2].y, nv[2].z, nv[2].w};
+      uint2 q4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q4[e].x = pack_bf16x2(p0[e], p1[e]);
+        q4[e].y = pack_bf16x2(p2[e], 0.f);
+      }
+      char* d = sP + (np % RING_ROWS) * ROW_B + pf_col;
+      *reinterpret_cast<uint2*>(d) = q4[0];
+      *reinterpret_cast<uint4*>(d + 8) = uint4{q4[1].x, q4[1].y, q4[2].x, q4[2].y};
+      *reinterpret_cast<uint2*>(d + 24) = q4[3];
+    }
+    __syncthreads();
+  }
+
+  // ---- statistics: the sixteen pixel lanes of a lane row, then the eight waves in wave order, one slot per workgroup
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      s1[k] += __shfl_xor(s1[k], off, 64);
+      s2[k] += __shfl_xor(s2[k], off, 64);
+    }
+  float* const sRed = reinterpret_cast<float*>(sP);   // [wave][sum 64 | sumsq 64]; the ring is dead (barrier above)
+  if (fr == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int ch = 16 * (k >> 2) + 4 * fq + (k & 3);
+      sRed[wave * 128 + ch] = s1[k];
+      sRed[wave * 128 + 64 + ch] = s2[k];
+    }
+  }
+  __syncthreads();
+  if (t < 128) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < 8; ++w_) tot += sRed[w_ * 128 + t];
+    stat_part[(long)blockIdx.x * 128 + t] = tot;
+  }
+}
+
 }  // namespace
 
 int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
@@ -584,3 +751,28 @@ extern "C" int rvit_debug_c1_stamps(unsigned long long* host_out, int n) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_c1_stamps), (size_t)n * 8);
 }
 #endif
+
+int rvit_stem_conv1_rows_impl(const float* x, const void* w, void* y, float* stat_ws, long stat_ws_bytes, int* stat_slots,
+                              int B, hipStream_t st) {
+  RVIT_CHECK_ARG(x && w && y && stat_ws && stat_slots && B > 0, "stem_conv1_rows: bad arguments");
+  RVIT_CHECK_ARG(rvit_aligned16(x) && rvit_aligned16(w) && rvit_aligned16(y) && rvit_aligned16(stat_ws),
+                 "stem_conv1_rows: operands must be 16-byte aligned");
+  int dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      n_cu <= 0)
+    n_cu = 256;
+  static const int divisors[6] = {1, 2, 4, 7, 14, 28};
+  int wpi = 28;
+  for (int d : divisors)
+    if ((long)B * d >= 2L * n_cu) { wpi = d; break; }
+  RVIT_CHECK_ARG((long)B * wpi * 128 * 4 <= stat_ws_bytes, "stem_conv1_rows: the statistics workspace holds %ld bytes, %ld needed",
+                 stat_ws_bytes, (long)B * wpi * 512);
+  RVIT_CHECK_ARG((long)B * wpi < 0x7fffffffL, "stem_conv1_rows: batch too large");
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)conv1_rows_roll_kernel}, ROLL_LDS, "stem_conv1_rows")) return rc;
+  hipLaunchKernelGGL(conv1_rows_roll_kernel, dim3((unsigned)(B * wpi)), dim3(512), ROLL_LDS, st, x, (const bf16*)w, (bf16*)y,
+                     stat_ws, wpi);
+  RVIT_CHECK_LAUNCH("stem_conv1_rows");
+  *stat_slots = B * wpi;
+  return RVIT_OK;
+}

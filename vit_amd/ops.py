@@ -323,6 +323,31 @@ def conv_stats_workspace(device, mbytes: int = 32) -> torch.Tensor:
     return torch.empty(mbytes * (1 << 18) + STAT_STAGE_FLOATS, dtype=torch.float32, device=device)
 
 
+def stem_conv1_stats_f32(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, sums: torch.Tensor,
+                         stat_ws: torch.Tensor) -> torch.Tensor:
+    """The stem's 7x7 / stride-2 conv of a training step straight from the fp32 NCHW input, with the batch statistics of
+    the stored map: x f32 [B,3,224,224], w bf16 [64,224], out bf16 [B,112,112,64], sums f32 [128] += (sum | sumsq)."""
+    _need_cuda(x, w, out, sums, stat_ws)
+    B = x.shape[0]
+    if x.shape != (B, 3, 224, 224) or x.dtype != torch.float32 or not x.is_contiguous() or w.shape != (64, 224) \
+            or w.dtype != BF16 or not w.is_contiguous() or out.shape != (B, 112, 112, 64) or out.dtype != BF16 \
+            or not out.is_contiguous():
+        raise ValueError("stem_conv1_stats_f32: bad operands")
+    _vec_f32(sums, 128, "stem_conv1_stats_f32: sums")
+    if stat_ws.dtype != torch.float32 or not stat_ws.is_contiguous() or stat_ws.numel() <= STAT_STAGE_FLOATS:
+        raise ValueError("stem_conv1_stats_f32: stat_ws must come from ops.conv_stats_workspace()")
+    lib = _lib.load()
+    slots = ctypes.c_int(0)
+    slot_floats = stat_ws.numel() - STAT_STAGE_FLOATS   # slots first, the finalisation's staging area behind them
+    with _Span("conv2d_gather", 2 * B * 112 * 112 * 64 * 147, _nbytes(x, w, out)):
+        check(lib.rvit_stem_conv1_stats_f32_fwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), stat_ws.data_ptr(), slot_floats * 4,
+                                                ctypes.byref(slots), B, _stream()), "rvit_stem_conv1_stats_f32_fwd")
+    with _Span("bn_stats_finalize", 0, slots.value * 128 * 4):
+        check(lib.rvit_bn_stats_finalize(stat_ws.data_ptr(), slots.value, 64, sums.data_ptr(),
+                                         stat_ws.data_ptr() + slot_floats * 4, _stream()), "rvit_bn_stats_finalize")
+    return out
+
+
 def conv2d_bn_stats(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, sums: torch.Tensor, stat_ws: torch.Tensor, *,
                     kh: int, kw: int, stride: int, pad: int, seg_len: Optional[int] = None,
                     bn_workspace: Optional[torch.Tensor] = None, tile: int = 0) -> bool:

@@ -249,6 +249,8 @@ class TrainEngine:
         self.ordered = os.environ.get("RVIT_ORDERED", "1") != "0"
         # stem bn1 backward with the max-pool gradient gathered in its two passes (0: maxpool_bwd + bn_bwd, for A/B runs)
         self.fused_pool_bwd = os.environ.get("RVIT_POOL_BWD_FUSED", "1") != "0"
+        # the stem's first conv by the rolling-band kernel from the fp32 input (0: implicit GEMM on the packed copy, A/B runs)
+        self.conv1_roll = os.environ.get("RVIT_CONV1_TRAIN_ROLL", "1") != "0"
         self.mb = None   # MobileStemTrainer for backbone='mobilenetv3'
         if getattr(model, "backbone_name", None) == "mobilenetv3":
             from .mobile_trainer import MobileStemTrainer
@@ -433,7 +435,7 @@ class TrainEngine:
         ops.bn_apply(y, fs, bn.weight.detach(), bn.bias.detach(), z, eps=bn.eps, relu=relu, residual=residual,
                      momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, relu_mask=mask)
 
-    def _stem_forward(self, P, b, B) -> torch.Tensor:
+    def _stem_forward(self, P, b, B, xin=None) -> torch.Tensor:
         cb = self.m.cnn_backbone
         b["fsums"].zero_()
         off = 0
@@ -441,8 +443,12 @@ class TrainEngine:
         ws = b["bn_ws"] if self.ordered_bn else None
         # stem entry: conv 7x7/2, then BatchNorm + ReLU + max-pool in one pass (the normalised 112x112 map is not
         # written: the backward pass needs only its sign bits and the argmax taps)
-        ops.conv2d_bn_stats(b["img"], P["conv1_w"], b["c1_y"], fs[off:off + 128], self._stat_ws(b["c1_y"].device), kh=7,
-                            kw=1, stride=2, pad=0, seg_len=32, bn_workspace=ws)
+        if self.conv1_roll and xin is not None and tuple(xin.shape[1:]) == (3, 224, 224):
+            # rolling-band kernel straight from the fp32 input, statistics in one slot per workgroup (same stored map)
+            ops.stem_conv1_stats_f32(xin, P["conv1_w"], b["c1_y"], fs[off:off + 128], self._stat_ws(b["c1_y"].device))
+        else:
+            ops.conv2d_bn_stats(b["img"], P["conv1_w"], b["c1_y"], fs[off:off + 128], self._stat_ws(b["c1_y"].device),
+                                kh=7, kw=1, stride=2, pad=0, seg_len=32, bn_workspace=ws)
         ops.bn_apply_pool(b["c1_y"], fs[off:off + 128], cb.bn1.weight.detach(), cb.bn1.bias.detach(), b["pool"],
                           b["pool_arg"], b["c1_m"], eps=cb.bn1.eps, momentum=cb.bn1.momentum,
                           running_mean=cb.bn1.running_mean, running_var=cb.bn1.running_var)
@@ -493,8 +499,8 @@ class TrainEngine:
                 feat = self.mb.forward(P["mb"], b["mb"], B, xin)
                 torch._foreach_add_(self._bn_counters(), 1)
             else:
-                ops.input_pack(xin, b["img"], 3, 3)
-                feat = self._stem_forward(P, b, B)
+                ops.input_pack(xin, b["img"], 3, 3)   # the 7x7 conv's weight gradient reads the packed copy
+                feat = self._stem_forward(P, b, B, xin)
             b["feat"] = feat
             ops.gemm(feat.view(B * NP, -1), P["pe_w"], x0.view(T, E), bias=m.patch_embed.bias.detach(),
                      residual=m.pos_embed.detach().view(S, E)[1:], residual_period=NP, row_group=NP, row_extra=1,
