@@ -93,6 +93,30 @@ __device__ __forceinline__ void red_commit(float* red, int C, int chunk, float (
 // ws: (64 + gridDim.x * 2 * C) floats, ws[0] zero before the first call; sequential calls on one stream may share it.
 __device__ __forceinline__ int det_slots(int C) { return (C >> 3) < 64 ? RED_THREADS / 64 : RED_THREADS / (C >> 3); }
 
+// p[0] + p[stride] + ... (n terms) added strictly in order, with up to 32 loads in flight: the partials come from HBM /
+// L2 at ~1 us a round trip and this runs in ONE workgroup at the tail of the kernel (eight in flight cost 8 round trips
+// for the 64 partials of a 512-channel map; the order of the additions, and so every bit, is the same)
+__device__ __forceinline__ float det_sum_run(const float* __restrict__ p, long stride, int n) {
+  float t = 0.f;
+  int k = 0;
+  for (; k + 32 <= n; k += 32) {
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = __builtin_nontemporal_load(p + (long)(k + j) * stride);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t += v[j];
+  }
+  for (; k + 8 <= n; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(p + (long)(k + j) * stride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t += v[j];
+  }
+  for (; k < n; ++k) t += __builtin_nontemporal_load(p + (long)k * stride);
+  return t;
+}
+
 __device__ __forceinline__ void red_commit_det(float* red, int C, int chunk, float (&a)[8], float (&b)[8],
                                                float* __restrict__ ws, float* __restrict__ sums) {
   __shared__ unsigned ticket;
@@ -130,7 +154,7 @@ __device__ __forceinline__ void red_commit_det(float* red, int C, int chunk, flo
   if (ticket != (unsigned)nblk - 1u) return;
   __threadfence();   // acquire: the other workgroups' partials
   // The last workgroup adds the partials in a fixed association: G thread groups each add a contiguous run of
-  // workgroups in order (eight loads in flight: the partials come from HBM at ~1 us a round trip), then the G group
+  // workgroups in order (det_sum_run: up to 32 loads in flight), then the G group
   // totals are added in group order.
   const float* all = ws + 64;
   if (cols <= RED_THREADS) {
@@ -138,16 +162,9 @@ __device__ __forceinline__ void red_commit_det(float* red, int C, int chunk, flo
     const int per = (nblk + G - 1) / G;
     float t = 0.f;
     if (g < G) {
-      int blk = g * per;
+      const int blk = g * per;
       const int end = blk + per < nblk ? blk + per : nblk;
-      for (; blk + 8 <= end; blk += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(all + (long)(blk + j) * cols + i);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t += v[j];
-      }
-      for (; blk < end; ++blk) t += __builtin_nontemporal_load(all + (long)blk * cols + i);
+      if (end > blk) t = det_sum_run(all + (long)blk * cols + i, cols, end - blk);
     }
     __syncthreads();   // the slot values in `red` are dead
     if (g < G) red[g * cols + i] = t;
@@ -158,19 +175,7 @@ __device__ __forceinline__ void red_commit_det(float* red, int C, int chunk, flo
       sums[i] += tot;
     }
   } else {
-    for (int i = threadIdx.x; i < cols; i += RED_THREADS) {
-      float t = 0.f;
-      int blk = 0;
-      for (; blk + 8 <= nblk; blk += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(all + (long)(blk + j) * cols + i);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t += v[j];
-      }
-      for (; blk < nblk; ++blk) t += __builtin_nontemporal_load(all + (long)blk * cols + i);
-      sums[i] += t;
-    }
+    for (int i = threadIdx.x; i < cols; i += RED_THREADS) sums[i] += det_sum_run(all + i, cols, nblk);
   }
   if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(ws) = 0u;   // re-armed for the next call on this stream
 }
