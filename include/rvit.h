@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 27
+#define RVIT_ABI_VERSION 28
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -147,6 +147,16 @@ int rvit_bn_stats_finalize(const void* stat_ws, int stat_slots, int C, float* su
  * packed image; one workgroup walks down an image (or a part of it), every input row is fetched once. */
 int rvit_stem_conv1_stats_f32_fwd(const float* x, const void* w, void* y, void* stat_ws, int64_t stat_ws_bytes,
                                   int* stat_slots, int B, void* stream);
+
+/* Weight gradient of that conv (autograd of `conv1` in loss.backward(), train_vit.py:949-955), from the same fp32 input:
+ *   dw[co][kh*32 + px*4 + ch] += sum over images and output pixels (r, c) of dy[b][r][c][co] * bf16(x[b][ch][2r+kh-3][2c+px-3])
+ * i.e. what rvit_conv2d_wgrad_bf16 gives on the packed image with seg_len 32 (the columns px = 7 and ch = 3 are not
+ * weights of the conv: px = 7 holds the products with the neighbouring pixel, ch = 3 zeros, as there), without the packed
+ * image being read 2 x 7 times.
+ *   dy: bf16 [B,112,112,64]; dw: fp32 [64, 224]; workspace: the ordered-reduction scratch (required: one slot of 64 x 224
+ *   floats per workgroup, >= B slots; added in slot order, so the result is the same on every run). */
+int rvit_stem_conv1_wgrad_f32(const float* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes, int B,
+                              void* stream);
 
 /* Which kernel rvit_conv2d_fwd_bf16 / rvit_conv2d_dgrad_bf16 run (tile 0) for a 3x3 / stride 1 / pad 1 convolution of B
  * images of H x W x Cin -> Cout (16-byte aligned operands): 0 implicit-GEMM gather kernel, 1 generic direct kernel

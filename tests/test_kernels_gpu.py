@@ -378,6 +378,40 @@ def test_stem_conv1_training_form(dev, B):
     assert torch.allclose(runs[0][64:] / n, want[64:] / n, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("B", [2, 37, 130, 256, 600])
+def test_stem_conv1_wgrad_roll(dev, B):
+    """rvit_stem_conv1_wgrad_f32 (round 3): weight gradient of the stem's 7x7 conv from the fp32 input on the rolling band,
+    against rvit_conv2d_wgrad_bf16 on the packed image (same bf16 products, another fp32 summation order) and, for the
+    small batch, torch's fp32 conv weight gradient; accumulates into dw; two runs identical (ordered slots)."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(100 + B)
+    x = (torch.randn(B, 3, 224, 224, generator=g) * 1.5).to(dev)
+    dy = _bf(torch.randn(B, 112, 112, 64, generator=g) / 64).to(dev)
+    img = torch.zeros(B, 230, 232, 4, dtype=torch.bfloat16, device=dev)
+    ops.input_pack(x, img, 3, 3)
+    ops.enable_ordered_reductions(dev)
+    want = torch.zeros(64, 224, device=dev)
+    ops.conv2d_wgrad(dy, img, want, kh=7, kw=1, stride=2, pad=0, seg_len=32)
+    base = torch.randn(64, 224, generator=g).to(dev)
+    runs = []
+    for _ in range(2):
+        dw = base.clone()
+        ops.stem_conv1_wgrad_f32(dy, x, dw)
+        runs.append(dw - base)
+    assert torch.equal(runs[0], runs[1])
+    scale = want.abs().max().item()
+    err = (runs[0] - want).abs().max().item()
+    assert err <= 2e-4 * scale + 1e-5, (err, scale)
+    if B <= 2:
+        xr = x.bfloat16().float().cpu().requires_grad_(False)
+        wr = torch.zeros(64, 3, 7, 7, requires_grad=True)
+        F.conv2d(xr, wr, None, 2, 3).backward(dy.float().cpu().permute(0, 3, 1, 2))
+        got = runs[0].view(64, 7, 8, 4)[:, :, :7, :3].permute(0, 3, 1, 2).cpu()
+        _close(got, wr.grad, 1e-3, 1e-3, "stem conv1 wgrad vs torch")
+    # unchanged operands
+    assert torch.isfinite(runs[0]).all()
+
+
 def _conv_ref(x_nhwc, w_ohwi, stride, pad):
     return F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w_ohwi.float().permute(0, 3, 1, 2), None, stride, pad)
 

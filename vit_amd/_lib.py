@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 27
+ABI_VERSION = 28
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "rvit_attn_fwd_fp8": ([P, P, L, P, I, I, I, L, F, P], c_int),
     "rvit_attn_fwd_mx": ([P, P, L, P, I, I, I, L, F, P], c_int),
     "rvit_stem_conv1_stats_f32_fwd": ([P, P, P, P, L, P, I, P], c_int),
+    "rvit_stem_conv1_wgrad_f32": ([P, P, P, P, L, I, P], c_int),
     "rvit_conv2d_fwd_stats_bf16": ([P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P, L, P, I, P], c_int),
     "rvit_bn_stats_finalize": ([P, I, I, P, P, P], c_int),
     "rvit_dwconv_fwd_bf16": ([P, P, P, P, P, I, I, I, I, I, I, I, I, P], c_int),

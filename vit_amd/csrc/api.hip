@@ -118,6 +118,11 @@ int rvit_stem_conv1_stats_f32_fwd(const float* x, const void* w, void* y, void* 
   return rvit_stem_conv1_rows_impl(x, w, y, (float*)stat_ws, stat_ws_bytes, stat_slots, B, (hipStream_t)stream);
 }
 
+int rvit_stem_conv1_wgrad_f32(const float* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes, int B,
+                              void* stream) {
+  return rvit_stem_conv1_wgrad_impl(x, dy, dw, (float*)workspace, workspace_bytes, B, (hipStream_t)stream);
+}
+
 int rvit_conv2d_fwd_stats_bf16(const void* x, const void* w, void* y, int B, int H, int W, int Cpix, int seg_len, int KH,
                                int KW, int stride, int pad, int Ho, int Wo, int Cout, void* stat_ws, int64_t stat_ws_bytes,
                                int* stat_slots, int tile, void* stream) {

@@ -694,6 +694,195 @@ __global__ __launch_bounds__(512, 4) void conv1_rows_roll_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same conv on the rolling band (round 3):
+//   dW[co][kh][px][ch] = sum over images, conv rows r, conv columns c of dY[r][c][co] * packed[2r + kh][2c + px][ch]
+// As an implicit GEMM (wgrad.hip, N = 64, K = 224) this ran two K tiles per M split that each streamed all of dY, one
+// 64-row tile per barrier: 330 us at B = 256 for 0.56 GB of operands.  Here a workgroup walks down an image as the
+// forward kernel does (same ring of packed rows built from the fp32 input, every input row fetched once), one conv row
+// per step: the row of dY (112 pixels x 64 channels) arrives by LDS-DMA, double-buffered, and wave kh contracts it with
+// the packed row 2r + kh over the pixels: both operands through the transposing LDS read (the contraction index is the
+// pixel: dY rows are 128 bytes apart, the windows of consecutive conv columns 16 bytes apart in the packed row - the
+// read takes one address per lane, so overlapping rows cost nothing).  Wave kh keeps dW[0..63][kh][0..31] in 32
+// registers for the whole walk; one partial slot of 64 x 224 floats per workgroup, added in slot order by
+// rvit_ordered_finalize.  dY rows are padded to 128 pixels with zeros (four 32-pixel MFMA steps).
+__device__ __forceinline__ int c1_swz(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }   // on 16-B chunks
+__device__ __forceinline__ bf16x4 c1_tr_read(const char* p) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p)));
+}
+constexpr int WG_YROW = 128 * 128;                       // bytes of one dY row image (128 pixels x 64 channels)
+constexpr int WG_YOFF = (RING_BYTES + 1023) & ~1023;     // the dY images start on a 1 KB boundary (LDS-DMA pieces)
+constexpr int WG_LDS = WG_YOFF + 2 * WG_YROW;            // 77,824: two workgroups per CU
+// LDS-DMA as inline assembly: hipcc's wait-count pass puts `s_waitcnt vmcnt(0)` in front of the first transposing LDS
+// read it sees while a global_load_lds IT issued is outstanding, which here would expose the latency of the next row's
+// request in every row.  The kernel's own waits + barriers order the accesses.  (m0 has no other user in this kernel.)
+__device__ __forceinline__ void c1_glds16_asm(const void* src, char* lds_dst_wave_base) {
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_char*)lds_dst_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m0v), "v"(src) : "memory");
+}
+
+__global__ __launch_bounds__(512, 4) void conv1_wgrad_roll_kernel(const float* __restrict__ xin, const bf16* __restrict__ dy,
+                                                                  float* __restrict__ part, int wpi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sP = smem;
+  char* const sY = smem + WG_YOFF;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x / wpi, seg = blockIdx.x - b * wpi;
+  const int nb = BANDS / wpi;
+  const int band0 = seg * nb;
+  const float* __restrict__ x = xin + (long)b * 3 * 224 * 224;
+  const bf16* __restrict__ dyb = dy + (long)b * WC * WC * 64;
+  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_page_c1);
+
+  // dY row `r` -> buffer `buf`: 14 pieces of 1 KB (8 pixels each); piece p: lane -> pixel 8p + (lane >> 3), 16-byte chunk
+  // slot lane & 7 holding source chunk slot ^ swz(pixel) (conflict-free transposing reads, as wgrad3x3.hip); waves 0-6 two
+  // pieces each.  Rows past the segment: zero pages (keeps the wait counts fixed).
+  auto issue_dy = [&](int r, int buf, bool live) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave * 2 + i;
+      if (piece < 14) {
+        const int pix = piece * 8 + (lane >> 3);
+        const bf16* src = live ? dyb + ((long)r * WC + pix) * 64 + (((lane & 7) ^ c1_swz(pix)) << 3) : zero_src;
+        c1_glds16_asm(src, sY + buf * WG_YROW + piece * 1024);
+      }
+    }
+  };
+
+  int c0 = 4 * band0;
+  const int r_end = c0 + 4 * nb;
+  // ---- zero the ring and the dY images (their pixels 112-127 stay zero), first window of packed rows ----
+  {
+    const int p_first = 2 * c0;
+    constexpr int UPT = 2;
+    float4 v[UPT][3];
+    int dst[UPT];
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      const int id = t + u * 512;
+      const int r = id / 56, j = id - r * 56;
+      const int p = p_first + r, ir = p - 3;
+      dst[u] = -1;
+      if (r < 13 && (unsigned)ir < 224u) {
+        const float* src = x + (long)ir * 224 + 4 * j;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[u][c] = *reinterpret_cast<const float4*>(src + (long)c * 224 * 224);
+        dst[u] = (p % RING_ROWS) * ROW_B + (4 * j + 3) * 8;
+      }
+    }
+    for (int i = t; i < WG_LDS / 16; i += 512) *reinterpret_cast<uint4*>(smem + i * 16) = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) {
+      if (dst[u] < 0) continue;
+      const float p0[4] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w};
+      const float p1[4] = {v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+      const float p2[4] = {v[u][2].x, v[u][2].y, v[u][2].z, v[u][2].w};
+      uint2 px[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        px[e].x = pack_bf16x2(p0[e], p1[e]);
+        px[e].y = pack_bf16x2(p2[e], 0.f);
+      }
+      char* d = sP + dst[u];
+      *reinterpret_cast<uint2*>(d) = px[0];
+      *reinterpret_cast<uint4*>(d + 8) = uint4{px[1].x, px[1].y, px[2].x, px[2].y};
+      *reinterpret_cast<uint2*>(d + 24) = px[3];
+    }
+  }
+  issue_dy(c0, 0, true);
+
+  // transposing-read geometry: within a 16-lane group lane (q, pp) supplies row q, columns 4 pp .. 4 pp + 3 of a 4 x 16
+  // block and receives rows 0..3 of column lane & 15; lane group g takes pixels 8 g .. 8 g + 7 of a 32-pixel step
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int pix0 = 8 * g + q;                                   // + 32 ks (+ 4 for the second read)
+  const int y_off = pix0 * 128 + (pp >> 1) * 16 + (pp & 1) * 8;  // + segment (co block ^ swizzle) << 5
+  const int y_sw = c1_swz(pix0) >> 1;                           // the same for pix0 + 4 and + 32 ks
+  const int x_off = pix0 * 16 + pp * 8;                          // + 32 col block, + 512 ks, + 64 for the second read
+  const int pf_r = t / 56, pf_j = t - pf_r * 56;
+  const int pf_col = (4 * pf_j + 3) * 8;
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 nv[3];
+  int np = 0;
+#pragma unroll 1
+  for (int r = c0; r < r_end; ++r) {
+    const int ri = r - c0;
+    const bool band_start = (ri & 3) == 0, band_end = (ri & 3) == 3;
+    const bool has_next_band = r + (4 - (ri & 3)) < r_end;
+    // this row's dY pieces have landed (every wave's, after the barrier); the other buffer is free again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (band_start && has_next_band && wave < 7) {
+      // request the 8 new packed rows of the next band (fp32, three planes) ahead of the pieces: the loop-top wait of the
+      // next row covers both.  Rows below the image re-read row 0 and are zeroed when they are packed (band end).
+      np = 2 * r + 13 + pf_r;
+      const float* src = x + (long)(np - 3 < 224 ? np - 3 : 0) * 224 + 4 * pf_j;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nv[c] = *reinterpret_cast<const float4*>(src + (long)c * 224 * 224);
+    }
+    issue_dy(r + 1, (ri + 1) & 1, r + 1 < r_end);
+    if (wave < 7) {
+      const char* const xrow = sP + ((2 * r + wave) % RING_ROWS) * ROW_B + x_off;
+      const char* const yrow = sY + (ri & 1) * WG_YROW + y_off;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 xf[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          const bf16x4 lo = c1_tr_read(xrow + ks * 512 + jb * 32);
+          const bf16x4 hi = c1_tr_read(xrow + ks * 512 + jb * 32 + 64);
+          xf[jb] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const char* yp = yrow + ks * 4096 + ((i ^ y_sw) << 5);
+          const bf16x4 lo = c1_tr_read(yp);
+          const bf16x4 hi = c1_tr_read(yp + 512);
+          const bf16x8 yf = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) acc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, xf[jb], acc[i][jb], 0, 0, 0);
+        }
+      }
+    }
+    if (band_end && has_next_band && wave < 7) {   // the next band's rows into the ring (not read by this band)
+      const float p0[4] = {nv[0].x, nv[0].y, nv[0].z, nv[0].w};
+      const float p1[4] = {nv[1].x, nv[1].y, nv[1].z, nv[1].w};
+      const float p2[4] = {nv[2].x, nv[2].y, nv[2].z, nv[2].w};
+      const bool in_img = np - 3 < 224;
+      uint2 q4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        q4[e].x = in_img ? pack_bf16x2(p0[e], p1[e]) : 0u;
+        q4[e].y = in_img ? pack_bf16x2(p2[e], 0.f) : 0u;
+      }
+      char* d = sP + (np % RING_ROWS) * ROW_B + pf_col;
+      *reinterpret_cast<uint2*>(d) = q4[0];
+      *reinterpret_cast<uint4*>(d + 8) = uint4{q4[1].x, q4[1].y, q4[2].x, q4[2].y};
+      *reinterpret_cast<uint2*>(d + 24) = q4[3];
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-page pieces requested past the last row
+
+  // ---- one slot per workgroup: lane holds dW[co = 16 i + 4 g + e][kh = wave][16 jb + (lane & 15)] ----
+  if (wave < 7) {
+    float* dst = part + (long)blockIdx.x * (64 * 224) + wave * 32 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(16 * i + 4 * g + e) * 224 + 16 * jb] = acc[i][jb][e];
+  }
+}
+
 }  // namespace
 
 int rvit_stem_conv1_pool_impl(const void* img, const void* w, const float* scale, const float* bias, void* pooled,
@@ -775,4 +964,34 @@ int rvit_stem_conv1_rows_impl(const float* x, const void* w, void* y, float* sta
   RVIT_CHECK_LAUNCH("stem_conv1_rows");
   *stat_slots = B * wpi;
   return RVIT_OK;
+}
+
+// dW[64][224] += the weight gradient of the stem's 7x7 conv; ws: one slot of 64 x 224 floats per workgroup
+int rvit_stem_conv1_wgrad_impl(const float* x, const void* dy, float* dw, float* ws, long ws_bytes, int B, hipStream_t st) {
+  RVIT_CHECK_ARG(x && dy && dw && ws && B > 0, "stem_conv1_wgrad: bad arguments");
+  RVIT_CHECK_ARG(rvit_aligned16(x) && rvit_aligned16(dy) && rvit_aligned16(dw) && rvit_aligned16(ws),
+                 "stem_conv1_wgrad: operands must be 16-byte aligned");
+  int dev = 0, n_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      n_cu <= 0)
+    n_cu = 256;
+  static const int divisors[6] = {1, 2, 4, 7, 14, 28};
+  int wpi = 28;
+  for (int d : divisors)
+    if ((long)B * d >= 2L * n_cu) { wpi = d; break; }
+  // fewer workgroups per image when the workspace is short of slots
+  while (wpi > 1 && (long)B * wpi * 64 * 224 * 4 > ws_bytes) {
+    int next = 1;
+    for (int d : divisors)
+      if (d < wpi) next = d;
+    wpi = next;
+  }
+  RVIT_CHECK_ARG((long)B * wpi * 64 * 224 * 4 <= ws_bytes, "stem_conv1_wgrad: the workspace holds %ld bytes, %ld needed", ws_bytes,
+                 (long)B * wpi * 64 * 224 * 4);
+  RVIT_CHECK_ARG((long)B * wpi < 0x7fffffffL, "stem_conv1_wgrad: batch too large");
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)conv1_wgrad_roll_kernel}, WG_LDS, "stem_conv1_wgrad")) return rc;
+  hipLaunchKernelGGL(conv1_wgrad_roll_kernel, dim3((unsigned)(B * wpi)), dim3(512), WG_LDS, st, x, (const bf16*)dy, ws, wpi);
+  RVIT_CHECK_LAUNCH("stem_conv1_wgrad");
+  return rvit_ordered_finalize(ws, B * wpi, 64L * 224, dw, 64, 224, 224, st);
 }

@@ -59,6 +59,7 @@ int rvit_conv3x3_auto(const GemmArgs& a);                     // conv3x3.hip: th
 bool rvit_conv3x3_p8_ok(const GemmArgs& a);                   // conv3x3_p8.hip (eight waves, four-phase taps, one workgroup per CU)
 bool rvit_conv3x3_p8_pays(const GemmArgs& a);                 // ... and its tiles / rounds are full enough to win
 int rvit_conv3x3_p8(const GemmArgs& a, hipStream_t stream);
+int rvit_stem_conv1_wgrad_impl(const float* x, const void* dy, float* dw, float* ws, long ws_bytes, int B, hipStream_t st);
 int rvit_stem_conv1_rows_impl(const float* x, const void* w, void* y, float* stat_ws, long stat_ws_bytes, int* stat_slots,
                               int B, hipStream_t st);   // conv1.hip
 bool rvit_conv3x3_c64_ok(const GemmArgs& a);                  // conv3x3_c64.hip (64 -> 64 channels, weights resident)

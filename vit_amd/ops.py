@@ -348,6 +348,25 @@ def stem_conv1_stats_f32(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, su
     return out
 
 
+def stem_conv1_wgrad_f32(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor) -> torch.Tensor:
+    """dw f32 [64,224] += weight gradient of the stem's 7x7 / stride-2 conv from the fp32 NCHW input x [B,3,224,224] and
+    dy bf16 [B,112,112,64] (column kh*32 + px*4 + ch, as conv2d_wgrad with seg_len 32 on the packed image).  Needs the
+    ordered-reduction workspace of the current stream (enable_ordered_reductions)."""
+    _need_cuda(dy, x, dw)
+    B = x.shape[0]
+    if x.shape != (B, 3, 224, 224) or x.dtype != torch.float32 or not x.is_contiguous() or dy.shape != (B, 112, 112, 64) \
+            or dy.dtype != BF16 or not dy.is_contiguous() or dw.shape != (64, 224) or dw.dtype != torch.float32 \
+            or not dw.is_contiguous():
+        raise ValueError("stem_conv1_wgrad_f32: bad operands")
+    ws, ws_bytes = _ows(dw)
+    if ws is None:
+        raise ValueError("stem_conv1_wgrad_f32: needs ops.enable_ordered_reductions() on this stream")
+    with _Span("conv2d_wgrad", 2 * B * 112 * 112 * 64 * 224, _nbytes(dy, x, dw)):
+        check(_lib.load().rvit_stem_conv1_wgrad_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws, ws_bytes, B, _stream()),
+              "rvit_stem_conv1_wgrad_f32")
+    return dw
+
+
 def conv2d_bn_stats(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, sums: torch.Tensor, stat_ws: torch.Tensor, *,
                     kh: int, kw: int, stride: int, pad: int, seg_len: Optional[int] = None,
                     bn_workspace: Optional[torch.Tensor] = None, tile: int = 0) -> bool:

@@ -251,6 +251,8 @@ class TrainEngine:
         self.fused_pool_bwd = os.environ.get("RVIT_POOL_BWD_FUSED", "1") != "0"
         # the stem's first conv by the rolling-band kernel from the fp32 input (0: implicit GEMM on the packed copy, A/B runs)
         self.conv1_roll = os.environ.get("RVIT_CONV1_TRAIN_ROLL", "1") != "0"
+        # ... and its weight gradient on the same band (ordered slots only; 0: implicit GEMM on the packed copy)
+        self.conv1_wgrad_roll = os.environ.get("RVIT_CONV1_WGRAD_ROLL", "1") != "0"
         self.mb = None   # MobileStemTrainer for backbone='mobilenetv3'
         if getattr(model, "backbone_name", None) == "mobilenetv3":
             from .mobile_trainer import MobileStemTrainer
@@ -499,7 +501,11 @@ class TrainEngine:
                 feat = self.mb.forward(P["mb"], b["mb"], B, xin)
                 torch._foreach_add_(self._bn_counters(), 1)
             else:
-                ops.input_pack(xin, b["img"], 3, 3)   # the 7x7 conv's weight gradient reads the packed copy
+                # both directions of the 7x7 conv read the fp32 input itself on the rolling band; otherwise the packed copy
+                b["xin"] = xin if (self.conv1_roll and self.conv1_wgrad_roll and self.ordered
+                                   and tuple(xin.shape[1:]) == (3, 224, 224)) else None
+                if b["xin"] is None:
+                    ops.input_pack(xin, b["img"], 3, 3)
                 feat = self._stem_forward(P, b, B, xin)
             b["feat"] = feat
             ops.gemm(feat.view(B * NP, -1), P["pe_w"], x0.view(T, E), bias=m.patch_embed.bias.detach(),
@@ -615,7 +621,10 @@ class TrainEngine:
                        self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"), eps=cb.bn1.eps,
                        relu=True, relu_mask=b["c1_m"], workspace=ws)
         dw1 = torch.zeros(64, 224, dtype=F32, device=dyc.device)
-        ops.conv2d_wgrad(dyc, b["img"], dw1, kh=7, kw=1, stride=2, pad=0, seg_len=32)
+        if b.get("xin") is not None:
+            ops.stem_conv1_wgrad_f32(dyc, b["xin"], dw1)
+        else:
+            ops.conv2d_wgrad(dyc, b["img"], dw1, kh=7, kw=1, stride=2, pad=0, seg_len=32)
         self._g(flat, "cnn_backbone.conv1.weight").view(64, 7, 7, 3).copy_(dw1.view(64, 7, 8, 4)[:, :, :7, :3])
 
     def _block_names(self):
