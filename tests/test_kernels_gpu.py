@@ -701,6 +701,39 @@ def test_stem_conv1_pool_rolling_band_splits(dev, B):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("name,cin,cout,hw,B,tile", [
+    ("c64", 64, 64, 56, 5, 0), ("c64-many-tiles", 64, 64, 56, 24, 0), ("direct64-l4", 512, 512, 7, 37, 0),
+    ("direct64-l3", 256, 256, 14, 3, 0), ("p8-128", 128, 128, 28, 256, 0), ("p8-256", 256, 256, 14, 256, 0),
+    ("p8-128-ragged", 128, 128, 28, 37, 19), ("p8-256-ragged", 256, 256, 14, 37, 19), ("c256", 512, 512, 7, 512, 0),
+    ("c256-ragged", 512, 512, 7, 5, 15), ("c256-l3", 256, 256, 14, 7, 15)])
+def test_conv3x3_direct_batch_statistics(dev, name, cin, cout, hw, B, tile):
+    """The statistics epilogue of the direct 3x3 kernels (round 3: conv3x3.hip, conv3x3_p8.hip, conv3x3_c64.hip): every
+    3x3 / stride 1 conv of a training step hands its BatchNorm sums over in per-tile slots.  Stored map bit-identical to
+    the plain conv's, sums equal to the exact sums of the stored map up to fp32 round-off, two runs identical."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(cin + hw + B)
+    x = torch.randn(B, hw, hw, cin, generator=g).to(torch.bfloat16).to(dev)
+    w = _bf(torch.randn(cout, 9 * cin, generator=g) / math.sqrt(9 * cin)).to(dev)
+    kw = dict(kh=3, kw=3, stride=1, pad=1, tile=tile)
+    y_ref = torch.empty(B, hw, hw, cout, dtype=torch.bfloat16, device=dev)
+    ops.conv2d(x, w, y_ref, **kw)
+    ws = ops.conv_stats_workspace(dev)
+    runs = []
+    for _ in range(2):
+        y = torch.full_like(y_ref, float("nan"))
+        sums = torch.zeros(2 * cout, device=dev)
+        fused = ops.conv2d_bn_stats(x, w, y, sums, ws, bn_workspace=ops.bn_workspace(dev), **kw)
+        assert fused, f"{name}: no statistics epilogue"
+        assert torch.equal(y, y_ref)
+        runs.append(sums)
+    assert torch.equal(runs[0], runs[1])
+    yf = y_ref.float().reshape(-1, cout).double()
+    exact = torch.cat([yf.sum(0), (yf ** 2).sum(0)]).float()
+    scale = torch.cat([yf.abs().sum(0), (yf ** 2).sum(0)]).float().clamp_min(1e-6)
+    err = ((runs[0] - exact).abs() / scale).max().item()
+    assert err <= 2e-5, err
+
+
 @pytest.mark.parametrize("case", ["conv1-7x7s2", "3x3s2", "1x1s2", "3x3s1-small"])
 def test_conv_epilogue_batch_statistics(dev, case):
     """rvit_conv2d_fwd_stats_bf16 (round 3): where the conv kernel has the statistics epilogue, the per-tile slots summed

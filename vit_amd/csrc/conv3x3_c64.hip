@@ -21,6 +21,7 @@
 // same layout.
 #include "common.h"
 #include "rvit_internal.h"
+#include "gemm_epilogue.h"
 #include <type_traits>
 
 namespace {
@@ -68,7 +69,7 @@ __device__ __forceinline__ int l1_desc(int row, int slot) {
   return (((pr - 1) * L1_W + (pc - 1)) * 64 + chunk * 8) | (pr == 0 ? 0 : (pr == L1_ROWS + 1 ? 2 : 1));
 }
 
-template <bool HAS_R, bool RELU, bool AFFINE>
+template <bool HAS_R, bool RELU, bool AFFINE, bool STATS = false>
 __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const GemmArgs p, int ntiles, int tiles_per_img) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wts = smem;
@@ -161,6 +162,12 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
   // after the row swap a lane owns channels pair*32 + (fq&1)*16 + (fq>>1)*8 .. +7 of pixel fr
   const int co_lane = (fq & 1) * 16 + (fq >> 1) * 8;
 
+  float st1[2][8], st2[2][8];   // STATS: this lane's 16 channels over every pixel it stores, all tiles of the workgroup
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st1[pr][e] = 0.f; st2[pr][e] = 0.f; }
+
   int buf = 0;
 #pragma unroll 1
   for (int tt = vb; tt < ntiles; tt += G, buf ^= 1) {
@@ -248,7 +255,40 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>((bf16*)p.C + (mbase + i * 16) * 64 + pr * 32 + co_lane) = o;
+        if constexpr (STATS) rvit_stat_acc8(o, st1[pr], st2[pr]);
       }
+    }
+  }
+  if constexpr (STATS) {
+    // batch statistics of everything this workgroup stored (GemmArgs::stat_part; the conv of a conv -> BatchNorm pair in
+    // a training step): the sixteen pixel lanes of a lane row on the vector ALU, the seven compute waves through LDS in
+    // wave order, one slot per workgroup.  The producer wave has left: the barriers below count the compute waves only.
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        st1[pr][e] = rvit_sum_row16(st1[pr][e]);
+        st2[pr][e] = rvit_sum_row16(st2[pr][e]);
+      }
+    __builtin_amdgcn_s_barrier();   // every compute wave is past its last fragment read
+    float* sred = reinterpret_cast<float*>(patch0);   // [wave][sum 64 | sumsq 64]
+    if (fr == 0) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sred[wave * 128 + pr * 32 + co_lane + e] = st1[pr][e];
+          sred[wave * 128 + 64 + pr * 32 + co_lane + e] = st2[pr][e];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t < 128) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < L1_CWAVES; ++w_) tot += sred[w_ * 128 + t];
+      p.stat_part[(long)blockIdx.x * 128 + t] = tot;
     }
   }
 #undef L1_DMA
@@ -270,6 +310,16 @@ static int c64_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
   if (const int rc = lim.ensure({(const void*)conv3x3_c64_kernel<HAS_R, RELU, AFFINE>}, L1_LDS, "conv3x3_c64")) return rc;
   const long ntiles = a.M / L1_TILE;
   const int grid = (int)(ntiles < n_cu ? ntiles : n_cu);
+  if constexpr (!HAS_R && !RELU && !AFFINE) {
+    if (rvit_conv_stats_wanted(a, grid)) {   // one slot per workgroup
+      static RvitLdsLimit lim_s;
+      if (const int rc = lim_s.ensure({(const void*)conv3x3_c64_kernel<false, false, false, true>}, L1_LDS, "conv3x3_c64")) return rc;
+      hipLaunchKernelGGL((conv3x3_c64_kernel<false, false, false, true>), dim3(grid), dim3(64 * L1_WAVES), L1_LDS, st, a, (int)ntiles, a.H / L1_ROWS);
+      RVIT_CHECK_LAUNCH("conv3x3_c64");
+      *a.stat_slots = grid;
+      return RVIT_OK;
+    }
+  }
   hipLaunchKernelGGL((conv3x3_c64_kernel<HAS_R, RELU, AFFINE>), dim3(grid), dim3(64 * L1_WAVES), L1_LDS, st, a, (int)ntiles, a.H / L1_ROWS);
   RVIT_CHECK_LAUNCH("conv3x3_c64");
   return RVIT_OK;

@@ -39,6 +39,7 @@
 
 #include "common.h"
 #include "rvit_internal.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -65,7 +66,7 @@ __device__ __forceinline__ int c8_fdiv(int m, int d, float inv_d) {
 constexpr int C8_MF = 7;        // pixel fragments per wave
 constexpr int C8_DUMMY = 8192;  // one dummy DMA slot per wave
 
-template <int TN>
+template <int TN, bool STATS = false>
 __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const int patch_bytes, const int tile_len,
                                                           const int ppw) {
   constexpr int WC = TN / 64;            // wave columns (64 channels each)
@@ -297,6 +298,11 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
   const int relu = p.act == RVIT_ACT_RELU;
   // every residual row of the wave is requested up front (the fragment registers are dead: 14 x 16 bytes per lane fit):
   // one exposed memory latency per tile instead of one per fragment row
+  float st1[2][8], st2[2][8];   // STATS: this lane's 16 channels over the pixels it stores
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st1[pr][e] = 0.f; st2[pr][e] = 0.f; }
   uint4 rr[C8_MF][2];
   if (has_r) {
 #pragma unroll
@@ -336,10 +342,43 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>((bf16*)p.C + (long)m * p.ldc + nl[pr]) = o;
+        if constexpr (STATS) rvit_stat_acc8(o, st1[pr], st2[pr]);
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of the (unused) tiles past the end must land before the LDS is released
+  if constexpr (STATS) {
+    // per-tile batch statistics (the conv of a conv -> BatchNorm pair in a training step, GemmArgs::stat_part): the
+    // sixteen pixel lanes of a lane row on the vector ALU, then the wave rows of a column block through LDS in wave
+    // order; one slot per M tile, fixed association, no atomics
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        st1[pr][e] = rvit_sum_row16(st1[pr][e]);
+        st2[pr][e] = rvit_sum_row16(st2[pr][e]);
+      }
+    __syncthreads();   // every wave is past its last fragment read: the patch buffers are free
+    float* sred = reinterpret_cast<float*>(smem);   // [wave][sum 64 | sumsq 64], channel = column inside the wave's 64
+    if (fr == 0) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          sred[wave * 128 + pr * 32 + co_lane + e] = st1[pr][e];
+          sred[wave * 128 + 64 + pr * 32 + co_lane + e] = st2[pr][e];
+        }
+    }
+    __syncthreads();
+    constexpr int WR = 8 / WC;
+    for (int idx = t; idx < WC * 128; idx += 512) {
+      const int wc_ = idx >> 7, q = idx & 127;
+      float tot = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WR; ++w_) tot += sred[(w_ * WC + wc_) * 128 + q];
+      p.stat_part[(long)tile_m * 2 * p.N + (q >> 6) * p.N + n0 + wc_ * 64 + (q & 63)] = tot;
+    }
+  }
 }
 
 struct C8Plan {
@@ -452,15 +491,22 @@ int rvit_conv3x3_p8(const GemmArgs& a, hipStream_t st) {
                  "conv3x3: the eight-wave four-phase kernel does not support this geometry");
   if (pl.tiles <= 0) return RVIT_OK;
   RVIT_CHECK_ARG(pl.tiles < 0x7fffffffL, "conv3x3: too many tiles");
+  const long mtiles = pl.tiles / (a.N / pl.tn);
+  const bool stats = rvit_conv_stats_wanted(a, mtiles);
+  static RvitLdsLimit lim;
+  if (const int rc = lim.ensure({(const void*)conv3x3_p8_kernel<256, false>, (const void*)conv3x3_p8_kernel<128, false>,
+                                 (const void*)conv3x3_p8_kernel<256, true>, (const void*)conv3x3_p8_kernel<128, true>},
+                                160 * 1024, "conv3x3_p8"))
+    return rc;
+#define C8_LAUNCH(TN_, S_) \
+  hipLaunchKernelGGL((conv3x3_p8_kernel<TN_, S_>), dim3((unsigned)pl.tiles), dim3(512), pl.lds, st, a, pl.patch_bytes, pl.tile_len, pl.ppw)
   if (pl.tn == 256) {
-    static RvitLdsLimit lim;
-    if (const int rc = lim.ensure({(const void*)conv3x3_p8_kernel<256>}, pl.lds, "conv3x3_p8")) return rc;
-    hipLaunchKernelGGL((conv3x3_p8_kernel<256>), dim3((unsigned)pl.tiles), dim3(512), pl.lds, st, a, pl.patch_bytes, pl.tile_len, pl.ppw);
+    if (stats) C8_LAUNCH(256, true); else C8_LAUNCH(256, false);
   } else {
-    static RvitLdsLimit lim;
-    if (const int rc = lim.ensure({(const void*)conv3x3_p8_kernel<128>}, pl.lds, "conv3x3_p8")) return rc;
-    hipLaunchKernelGGL((conv3x3_p8_kernel<128>), dim3((unsigned)pl.tiles), dim3(512), pl.lds, st, a, pl.patch_bytes, pl.tile_len, pl.ppw);
+    if (stats) C8_LAUNCH(128, true); else C8_LAUNCH(128, false);
   }
+#undef C8_LAUNCH
   RVIT_CHECK_LAUNCH("conv3x3_p8");
+  if (stats) *a.stat_slots = (int)mtiles;
   return RVIT_OK;
 }

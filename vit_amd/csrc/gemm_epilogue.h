@@ -221,6 +221,23 @@ __device__ __forceinline__ void rvit_stat_acc8(const uint4& o, float (&s1)[8], f
   for (int e = 0; e < 8; ++e) { s1[e] += x[e]; s2[e] = fmaf(x[e], x[e], s2[e]); }
 }
 
+// x summed over the sixteen lanes of a DPP row (lanes 16 k .. 16 k + 15): four row rotations on the vector ALU, every lane
+// gets a total (lane-dependent association, fixed from run to run; callers read one lane per row).
+__device__ __forceinline__ float rvit_sum_row16(float x) {
+  x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+  x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+  x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+  x += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+  return x;
+}
+
+// Does a conv launch with `slots` M tiles write the per-tile BatchNorm statistics (GemmArgs::stat_part)?  Only the plain
+// conv of a conv -> BatchNorm pair: no scale / bias / residual / activation, forward direction, slots within the workspace.
+static inline bool rvit_conv_stats_wanted(const GemmArgs& a, long slots) {
+  return a.stat_part && a.stat_slots && !a.scale && !a.bias && !a.R && a.act == RVIT_ACT_NONE && !a.transposed && slots > 0 &&
+         slots <= a.stat_cap_slots;
+}
+
 // x summed over the eight lanes l ^ {0, 8, 16, 24, 32, 40, 48, 56} (every lane gets the total; fixed association):
 // DPP row_ror:8 inside the 16-lane row, v_permlane16_swap between rows 0 <-> 1 and 2 <-> 3, v_permlane32_swap between
 // the wave halves.
