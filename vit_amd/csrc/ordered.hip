@@ -70,6 +70,48 @@ __global__ __launch_bounds__(256) void ordered_finalize_wide_kernel(const float*
   if (ok && g == 0) out[r * ld + c] += t;
 }
 
+// Mid-sized outputs (a 64 x 576 conv weight gradient over 256 slots: 36 workgroups of the kernel above, every thread a
+// chain of 64 dependent rounds of loads: 21 us): a workgroup owns 256 / SG float4 columns, thread group g adds the slots
+// g, g + SG, ... (eight loads in flight), the groups are combined through LDS in group order.  One association per run.
+template <int SG>
+__global__ __launch_bounds__(256) void ordered_finalize_grouped_kernel(const float* __restrict__ part, int nslots, long slot_stride,
+                                                                       float* __restrict__ out, long rows, int cols, long ld) {
+  constexpr int CW = 256 / SG;
+  __shared__ float4 red[SG][CW];
+  const int c = threadIdx.x % CW, g = threadIdx.x / CW;
+  const long per_row = cols / 4;
+  const long i = (long)blockIdx.x * CW + c;
+  const bool ok = i < rows * per_row;
+  const long r = ok ? i / per_row : 0;
+  const int col = ok ? (int)(i - r * per_row) * 4 : 0;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    const float* src = part + r * cols + col;
+    int s = g;
+    for (; s + 7 * SG < nslots; s += 8 * SG) {
+      f32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)(s + j * SG) * slot_stride));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { t.x += v[j][0]; t.y += v[j][1]; t.z += v[j][2]; t.w += v[j][3]; }
+    }
+    for (; s < nslots; s += SG) {
+      const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)s * slot_stride));
+      t.x += u[0]; t.y += u[1]; t.z += u[2]; t.w += u[3];
+    }
+  }
+  red[g][c] = t;
+  __syncthreads();
+  if (g == 0 && ok) {
+#pragma unroll
+    for (int k = 1; k < SG; ++k) { t.x += red[k][c].x; t.y += red[k][c].y; t.z += red[k][c].z; t.w += red[k][c].w; }
+    float* dst = out + r * ld + col;
+    float4 o = *reinterpret_cast<float4*>(dst);
+    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+    *reinterpret_cast<float4*>(dst) = o;
+  }
+}
+
 // First stage for very many slots (the per-tile statistics of the stem's first conv: 12,544 slots of 128 columns at
 // B = 256): workgroup g adds the slots [g * per, (g + 1) * per) in slot order (eight loads in flight) and stores one
 // slot of a G times smaller array; the second stage is the kernel above.  A fixed association on every run.
@@ -128,6 +170,18 @@ int rvit_ordered_finalize(const float* part, int nslots, long slot_stride, float
   const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && (slot_stride & 3) == 0 && rvit_aligned16(part) && rvit_aligned16(out);
   const long n = rows * (vec ? cols / 4 : cols);
   RVIT_CHECK_ARG((n + 255) / 256 < 0x7fffffffL, "ordered_finalize: too many elements");
+  if (vec && nslots >= 32 && n <= 8192) {          // up to 512 workgroups of 16 columns x 16 slot groups
+    hipLaunchKernelGGL(ordered_finalize_grouped_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, nslots, slot_stride,
+                       out, rows, cols, ld);
+    RVIT_CHECK_LAUNCH("ordered_finalize");
+    return RVIT_OK;
+  }
+  if (vec && nslots >= 16 && n <= 65536) {         // up to 1024 workgroups of 64 columns x 4 slot groups
+    hipLaunchKernelGGL(ordered_finalize_grouped_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, nslots, slot_stride,
+                       out, rows, cols, ld);
+    RVIT_CHECK_LAUNCH("ordered_finalize");
+    return RVIT_OK;
+  }
   const dim3 grid((unsigned)((n + 255) / 256));
   if (vec) hipLaunchKernelGGL(ordered_finalize_kernel<true>, grid, dim3(256), 0, st, part, nslots, slot_stride, out, rows, cols, ld);
   else hipLaunchKernelGGL(ordered_finalize_kernel<false>, grid, dim3(256), 0, st, part, nslots, slot_stride, out, rows, cols, ld);
