@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RVIT_ABI_VERSION 28
+#define RVIT_ABI_VERSION 29
 
 #define RVIT_BF16 0
 #define RVIT_F32 1
@@ -173,6 +173,21 @@ int rvit_conv3x3_kernel(int B, int H, int W, int Cin, int Cout);
 int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int KH, int KW,
                            int stride, int pad, int Hx, int Wx, int Cin, const void* residual, int tile,
                            void* stream);
+
+/* rvit_conv2d_dgrad_bf16 whose output dx is the gradient entering a train-mode BatchNorm (+ ReLU): the conv -> norm ->
+ * ReLU chains of timm's BasicBlock under loss.backward() (train_vit.py:87,949-955).  Where the chosen kernel has the
+ * hook (the direct 3x3 / stride 1 kernels), its epilogue also writes that norm's two backward sums over the rows of each
+ * tile - what rvit_bn_bwd_reduce computes from dx, bn_y and the ReLU bits in a pass of its own - to per-tile slots in
+ * stat_ws (layout of rvit_conv2d_fwd_stats_bf16: sum d | rstd * sum d (y - mean) per channel, d = the stored bf16
+ * gradient where the ReLU bit is set); rvit_bn_stats_finalize(stat_ws, *stat_slots, Cin, bwd_sums, stage) then adds them
+ * in order and rvit_bn_bwd_apply follows.  *stat_slots == 0: no hook for this geometry, dx is complete, the caller runs
+ * rvit_bn_bwd_reduce.
+ *   bn_y: the norm's input map, bf16 [B,Hx,Wx,Cin]; bn_relu_mask: the bits rvit_bn_apply wrote (one byte per 8 channels)
+ *   or NULL (no ReLU); bn_fwd_sums: fp32 [2 Cin] forward sums of that norm; eps: its epsilon. */
+int rvit_conv2d_dgrad_bnr_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int KH, int KW,
+                               int stride, int pad, int Hx, int Wx, int Cin, const void* residual, const void* bn_y,
+                               const void* bn_relu_mask, const float* bn_fwd_sums, float eps, void* stat_ws,
+                               int64_t stat_ws_bytes, int* stat_slots, void* stream);
 
 /* Input gradient of a 3x3 / stride 2 / pad 1 conv (the first conv of resnet layers 2-4, train_vit.py:87 through
  * autograd), decomposed by output parity into four dense stride-1 convs over dY (9 taps of work instead of 36):

@@ -319,6 +319,63 @@ def test_ce_loss(dev):
     assert float(dlb[:, C:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("name,c,hw,B,res,relu", [
+    ("c64", 64, 56, 5, False, True), ("c64-res", 64, 56, 24, True, True), ("direct64-l4", 512, 7, 37, True, True),
+    ("direct64-l3", 256, 14, 3, False, False), ("p8-128", 128, 28, 256, True, True), ("p8-256", 256, 14, 256, False, True),
+    ("c256", 512, 7, 512, True, True)])
+def test_dgrad_with_bn_backward_sums(dev, name, c, hw, B, res, relu):
+    """rvit_conv2d_dgrad_bnr_bf16 (round 3): the 3x3 dgrad whose output enters a BatchNorm's backward pass writes that
+    pass's two sums from its epilogue.  dx bit-identical to rvit_conv2d_dgrad_bf16's; the sums equal to those of the
+    stored dx (exact arithmetic in float64) up to fp32 round-off, and to rvit_bn_bwd_reduce's; two runs identical."""
+    from vit_amd import ops
+    g = torch.Generator().manual_seed(c + hw + B)
+    dy = _bf(torch.randn(B, hw, hw, c, generator=g) / 8).to(dev)
+    w_t = _bf(torch.randn(c, 9 * c, generator=g) / math.sqrt(9 * c)).to(dev)
+    r = _bf(torch.randn(B, hw, hw, c, generator=g) / 4).to(dev) if res else None
+    y = _bf(torch.randn(B, hw, hw, c, generator=g) * 1.3 + 0.2).to(dev)
+    M = B * hw * hw
+    mask = torch.randint(0, 256, (M * (c // 8),), generator=g, dtype=torch.uint8).to(dev) if relu else None
+    yf = y.float().reshape(M, c)
+    fs = torch.cat([yf.sum(0), (yf * yf).sum(0)]).contiguous()
+    eps = 1e-5
+    dx_ref = torch.empty(B, hw, hw, c, dtype=torch.bfloat16, device=dev)
+    ops.conv2d_dgrad(dy, w_t, dx_ref, kh=3, kw=3, stride=1, pad=1, residual=r)
+    ws = ops.conv_stats_workspace(dev)
+    runs = []
+    for _ in range(2):
+        dx = torch.full_like(dx_ref, float("nan"))
+        bs = torch.zeros(2 * c, device=dev)
+        fused = ops.conv2d_dgrad_bn_sums(dy, w_t, dx, kh=3, kw=3, stride=1, pad=1, residual=r, bn_y=y, bn_relu_mask=mask,
+                                         bn_fwd_sums=fs, bn_bwd_sums=bs, eps=eps, stat_ws=ws)
+        assert fused, f"{name}: no hook"
+        assert torch.equal(dx, dx_ref)
+        runs.append(bs)
+    assert torch.equal(runs[0], runs[1])
+    d = dx_ref.double().reshape(M, c)
+    if relu:
+        bits = ((mask.reshape(M, c // 8, 1).int() >> torch.arange(8, device=dev).int()) & 1).reshape(M, c)
+        d = d * bits
+    mean = (fs[:c] / M).double()
+    var = (fs[c:] / M).double() - mean * mean
+    rstd = 1.0 / torch.sqrt(var.clamp_min(0) + eps)
+    yc = yf.double() - mean
+    exact = torch.cat([d.sum(0), rstd * (d * yc).sum(0)]).float()
+    scale = torch.cat([d.abs().sum(0), rstd * (d * yc).abs().sum(0)]).float().clamp_min(1e-6)
+    err = ((runs[0] - exact).abs() / scale).max().item()
+    assert err <= 2e-5, err
+    # and the pass it replaces
+    dyo = torch.empty_like(dx_ref)
+    bs2 = torch.zeros(2 * c, device=dev)
+    ops.bn_bwd(dx_ref, None, y, fs, bs2, torch.ones(c, device=dev), dyo, torch.zeros(c, device=dev), torch.zeros(c, device=dev),
+               eps=eps, relu=relu, relu_mask=mask, workspace=ops.bn_workspace(dev))
+    err2 = ((runs[0] - bs2).abs() / scale).max().item()
+    assert err2 <= 4e-5, err2
+    dyf = torch.empty_like(dx_ref)
+    ops.bn_bwd(dx_ref, None, y, fs, runs[0].clone(), torch.ones(c, device=dev), dyf, torch.zeros(c, device=dev),
+               torch.zeros(c, device=dev), eps=eps, relu=relu, relu_mask=mask, reduced=True)
+    assert (dyf.float() - dyo.float()).abs().max().item() <= 2.0 ** -7 * dyo.float().abs().max().item()
+
+
 def test_colsum_and_batch_sum(dev):
     from vit_amd import ops
     g = torch.Generator().manual_seed(6)
@@ -330,6 +387,15 @@ def test_colsum_and_batch_sum(dev):
     o2 = torch.ones(50 * 64, device=dev)
     ops.batch_sum(x.to(dev), o2)
     _close(o2, 1 + x.sum(0), 1e-5, 1e-5, "batch_sum")
+    for B, n in ((300, 4 * 37), (129, 64), (1, 12800), (257, 50 * 256)):   # ragged column blocks, several row rounds
+        x = torch.randn(B, n, generator=g)
+        runs = []
+        for _ in range(2):
+            o = torch.ones(n, device=dev)
+            ops.batch_sum(x.to(dev), o)
+            runs.append(o)
+        assert torch.equal(runs[0], runs[1])
+        _close(runs[0], 1 + x.double().sum(0).float(), 1e-5, 2e-5, f"batch_sum {B}x{n}")
 
 
 def test_gemm_gate_and_a_remap(dev):

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "librvit.so")
 RVIT_BF16, RVIT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 GATE_NONE, GATE_GELU_GRAD, GATE_RELU_MASK = 0, 1, 2
-ABI_VERSION = 28
+ABI_VERSION = 29
 DROP_PRE_RESIDUAL, DROP_POST_ACT = 1, 2
 
 
@@ -40,6 +40,7 @@ SIGNATURES = {
     "rvit_conv2d_fwd_bf16": ([P, P, P] + [I] * 12 + [P, P, P, I, I, P], c_int),
     "rvit_conv3x3_kernel": ([I, I, I, I, I], c_int),
     "rvit_conv2d_dgrad_bf16": ([P, P, P] + [I] * 11 + [P, I, P], c_int),
+    "rvit_conv2d_dgrad_bnr_bf16": ([P, P, P] + [I] * 11 + [P, P, P, P, c_float, P, L, P, P], c_int),
     "rvit_conv2d_dgrad_s2_bf16": ([P, P, P, I, I, I, I, I, P, P], c_int),
     "rvit_conv1x1_dgrad_s2_acc_bf16": ([P, P, P, I, I, I, I, I, P], c_int),
     "rvit_conv2d_tokens_fwd": ([P, P, P] + [I] * 12 + [P, P, F, U64, I, P], c_int),

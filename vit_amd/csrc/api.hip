@@ -174,6 +174,35 @@ int rvit_conv2d_dgrad_bf16(const void* dy, const void* w_t, void* dx, int B, int
   return rvit_gemm_dispatch(a, (hipStream_t)stream);
 }
 
+int rvit_conv2d_dgrad_bnr_bf16(const void* dy, const void* w_t, void* dx, int B, int Hy, int Wy, int Cout, int KH, int KW,
+                               int stride, int pad, int Hx, int Wx, int Cin, const void* residual, const void* bn_y,
+                               const void* bn_relu_mask, const float* bn_fwd_sums, float eps, void* stat_ws,
+                               int64_t stat_ws_bytes, int* stat_slots, void* stream) {
+  RVIT_CHECK_ARG(B > 0 && Hy > 0 && Wy > 0 && Hx > 0 && Wx > 0 && KH > 0 && KW > 0 && pad >= 0, "conv dgrad: bad geometry");
+  RVIT_CHECK_ARG((long)B * Hy * Wy < 0x7fffffffL && (long)B * Hx * Wx < 0x7fffffffL, "conv dgrad: too many pixels");
+  RVIT_CHECK_ARG((Cout & 63) == 0, "conv dgrad: Cout=%d must be a multiple of 64", Cout);
+  RVIT_CHECK_ARG(bn_y && bn_fwd_sums && stat_ws && stat_slots && aligned_to(bn_y, 16) && aligned_to(stat_ws, 16) &&
+                     stat_ws_bytes >= 0 && (Cin & 7) == 0,
+                 "conv dgrad (bn sums): norm input / forward sums / workspace / slot count missing or misaligned");
+  GemmArgs a{};
+  conv_geometry(a, dy, w_t, B, Hy, Wy, Cout, Cout, KH, KW, stride, pad, Hx, Wx, Cin);
+  a.transposed = 1;
+  a.C = dx; a.ldc = Cin; a.c_f32 = 0;
+  a.R = residual; a.ldr = Cin; a.r_f32 = 0;
+  a.tile = 0;
+  a.vec = (Cin & 7) == 0 && aligned_to(dx, 16) && (!residual || aligned_to(residual, 16));
+  a.stat_part = (float*)stat_ws;
+  a.stat_cap_slots = (long)(stat_ws_bytes / 4 / (2L * Cin));
+  a.stat_slots = stat_slots;
+  a.bnr_y = (const bf16*)bn_y;
+  a.bnr_mask = (const uint8_t*)bn_relu_mask;
+  a.bnr_fsums = bn_fwd_sums;
+  a.bnr_inv_m = 1.0f / (float)((long)B * Hx * Wx);
+  a.bnr_eps = eps;
+  *stat_slots = 0;
+  return rvit_gemm_dispatch(a, (hipStream_t)stream);
+}
+
 int rvit_conv2d_dgrad_s2_bf16(const void* dy, const void* w_s2, void* dx, int B, int Hy, int Wy, int Cout, int Cin,
                               const void* residual, void* stream) {
   // Input gradient of a 3x3 / stride 2 / pad 1 conv by output parity.  dX pixel (2i+ph, 2j+pw) only receives the taps

@@ -81,9 +81,10 @@ constexpr int C3_PMAX = 640;  // patch pixels a workgroup can stage (DMA pass bu
 // 64-column LDS staging area so that whole 128-byte row segments reach global memory; folded-BN scale/bias,
 // residual, ReLU.  Ends the main loop with a workgroup barrier (the staging aliases patch and weight ring).
 // EP_ROWS: rows restaged per pass (the whole wave tile, or 16 at a time when sixteen waves share the LDS).
-// STATS (the conv of a conv -> BatchNorm pair in a training step, GemmArgs::stat_part): per-channel sum and sum of squares
-// of the bf16 values stored, one slot per M tile, as gemm.hip's epilogue writes them.
-template <int MR, int WM, int EP_ROWS = WM, int WAVES_M = 1, int WAVES_N = 1, bool STATS = false>
+// STATS 1 (the conv of a conv -> BatchNorm pair in a training step, GemmArgs::stat_part): per-channel sum and sum of squares
+// of the bf16 values stored, one slot per M tile, as gemm.hip's epilogue writes them.  STATS 2 (a dgrad conv whose output
+// enters a BatchNorm's backward pass, GemmArgs::bnr_y): that pass's two sums instead.
+template <int MR, int WM, int EP_ROWS = WM, int WAVES_M = 1, int WAVES_N = 1, int STATS = 0>
 __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4 (&acc)[MR][4], int wave, int lane, int wm,
                                             int wn, long m0, long m_last, int n0, int tile_m = 0) {
   const int fr = lane & 15, fq = lane >> 4;
@@ -93,9 +94,13 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
   const int er = lane >> 3, ec = (lane & 7) * 8;
   const int n = n0 + wn * 64 + ec;
   float sc[8], bi[8];
-  float st1[8], st2[8];
+  float st1[8], st2[8], bmean[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; bi[e] = 0.f; st1[e] = 0.f; st2[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { sc[e] = 1.f; bi[e] = 0.f; st1[e] = 0.f; st2[e] = 0.f; bmean[e] = 0.f; }
+  if constexpr (STATS == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bmean[e] = p.bnr_fsums[n + e] * p.bnr_inv_m;
+  }
   if (p.scale) {
     const float4 a = *reinterpret_cast<const float4*>(p.scale + n), b = *reinterpret_cast<const float4*>(p.scale + n + 4);
     sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
@@ -126,6 +131,17 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
       rr[pass] = *reinterpret_cast<const uint4*>((const bf16*)p.R + m * p.ldr + n);
     }
   }
+  uint4 yy[STATS == 2 ? EP_ROWS / 8 : 1];
+  unsigned ym[STATS == 2 ? EP_ROWS / 8 : 1];
+  if constexpr (STATS == 2) {   // the norm's input rows and ReLU bits, requested with the residual rows
+#pragma unroll
+    for (int pass = 0; pass < EP_ROWS / 8; ++pass) {
+      long m = m0 + wm * WM + i0 * 16 + pass * 8 + er;
+      if (m > m_last) m = m_last;
+      yy[pass] = *reinterpret_cast<const uint4*>(p.bnr_y + m * p.N + n);
+      ym[pass] = p.bnr_mask ? p.bnr_mask[m * (p.N >> 3) + (n >> 3)] : 0xffu;
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < EP_ROWS / 8; ++pass) {
     const int row = pass * 8 + er;
@@ -152,10 +168,11 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
     o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
     o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>((bf16*)p.C + m * p.ldc + n) = o;
-    if constexpr (STATS) rvit_stat_acc8(o, st1, st2);
+    if constexpr (STATS == 1) rvit_stat_acc8(o, st1, st2);
+    if constexpr (STATS == 2) rvit_bnr_acc8(o, yy[pass], ym[pass], bmean, st1, st2);
   }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS != 0) {
     // lanes that share a column chunk (l ^ 8, 16, 32) on the vector ALU, the waves of a column block through LDS in wave
     // order: one association on every run (rvit_bn_stats_finalize adds the slots in order)
 #pragma unroll
@@ -178,7 +195,9 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
       float tot = 0.f;
 #pragma unroll
       for (int w_ = 0; w_ < WAVES_M; ++w_) tot += sred[(w_ * WAVES_N + wn_) * 128 + q];
-      p.stat_part[(long)tile_m * 2 * p.N + (q >> 6) * p.N + n0 + wn_ * 64 + (q & 63)] = tot;
+      const int col = n0 + wn_ * 64 + (q & 63);
+      if (STATS == 2 && q >= 64) tot *= rvit_bnr_rstd(p.bnr_fsums, p.N, col, p.bnr_inv_m, p.bnr_eps);
+      p.stat_part[(long)tile_m * 2 * p.N + (q >> 6) * p.N + col] = tot;
     }
   }
 }
@@ -195,7 +214,7 @@ __device__ __forceinline__ void c3_epilogue(const GemmArgs& p, char* smem, f32x4
 // RING: stages of the weight-tile ring.  The tile of tap s + RING - 1 is issued at tap s, so RING - 1 tiles (8-32 KB)
 // are in flight per workgroup: with RING = 2 a tile has exactly one tap (~500 MFMA clocks per SIMD) to cross
 // L2 -> LDS, which is about the latency of an LDS-DMA under load, and every tap stalled on it.
-template <int BN, bool DB, int C3_WAVES, int RING = 2, bool STATS = false>
+template <int BN, bool DB, int C3_WAVES, int RING = 2, int STATS = 0>
 __global__ __launch_bounds__(64 * C3_WAVES, (BN == 64 && C3_WAVES == 8) ? 4 : 2) void conv3x3_direct_kernel(const GemmArgs p, int patch_bytes, int tile_len, int ablate) {
   static_assert(RING >= 2 && (RING == 2 || !DB), "deep weight rings are built for the single-patch-buffer variants");
   constexpr int WAVES_N = BN / 64, WAVES_M = C3_WAVES / WAVES_N;
@@ -478,10 +497,16 @@ static int c3_launch(const GemmArgs& a, int patch_bytes, int tile_len, hipStream
   RVIT_CHECK_ARG(tiles < 0x7fffffffL, "conv3x3: too many tiles");
   // the statistics epilogue exists for the variants the automatic choice runs in a training step
   if constexpr (!DB && ((BN == 64 && C3_WAVES == 8 && RING == 2) || BN == 256)) {
-    if (rvit_conv_stats_wanted(a, mtiles)) {
+    const int smode = rvit_conv_stat_mode(a, mtiles);
+    if (smode != 0) {
       static RvitLdsLimit lim_s;
-      if (const int rc = lim_s.ensure({(const void*)conv3x3_direct_kernel<BN, DB, C3_WAVES, RING, true>}, lds, "conv3x3")) return rc;
-      hipLaunchKernelGGL((conv3x3_direct_kernel<BN, DB, C3_WAVES, RING, true>), dim3((unsigned)tiles), dim3(64 * C3_WAVES), lds, st, a, patch_bytes, tile_len, c3_ablate());
+      if (const int rc = lim_s.ensure({(const void*)conv3x3_direct_kernel<BN, DB, C3_WAVES, RING, 1>,
+                                       (const void*)conv3x3_direct_kernel<BN, DB, C3_WAVES, RING, 2>}, lds, "conv3x3"))
+        return rc;
+      if (smode == 1)
+        hipLaunchKernelGGL((conv3x3_direct_kernel<BN, DB, C3_WAVES, RING, 1>), dim3((unsigned)tiles), dim3(64 * C3_WAVES), lds, st, a, patch_bytes, tile_len, c3_ablate());
+      else
+        hipLaunchKernelGGL((conv3x3_direct_kernel<BN, DB, C3_WAVES, RING, 2>), dim3((unsigned)tiles), dim3(64 * C3_WAVES), lds, st, a, patch_bytes, tile_len, c3_ablate());
       RVIT_CHECK_LAUNCH("conv3x3_direct");
       *a.stat_slots = (int)mtiles;
       return RVIT_OK;

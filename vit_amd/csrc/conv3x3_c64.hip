@@ -69,7 +69,7 @@ __device__ __forceinline__ int l1_desc(int row, int slot) {
   return (((pr - 1) * L1_W + (pc - 1)) * 64 + chunk * 8) | (pr == 0 ? 0 : (pr == L1_ROWS + 1 ? 2 : 1));
 }
 
-template <bool HAS_R, bool RELU, bool AFFINE, bool STATS = false>
+template <bool HAS_R, bool RELU, bool AFFINE, int STATS = 0>
 __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const GemmArgs p, int ntiles, int tiles_per_img) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wts = smem;
@@ -163,10 +163,14 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
   const int co_lane = (fq & 1) * 16 + (fq >> 1) * 8;
 
   float st1[2][8], st2[2][8];   // STATS: this lane's 16 channels over every pixel it stores, all tiles of the workgroup
+  float bmean[2][8];            // STATS 2 (GemmArgs::bnr_y): the BatchNorm backward sums instead
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { st1[pr][e] = 0.f; st2[pr][e] = 0.f; }
+    for (int e = 0; e < 8; ++e) {
+      st1[pr][e] = 0.f; st2[pr][e] = 0.f;
+      bmean[pr][e] = STATS == 2 ? p.bnr_fsums[pr * 32 + co_lane + e] * p.bnr_inv_m : 0.f;
+    }
 
   int buf = 0;
 #pragma unroll 1
@@ -183,6 +187,17 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr)
           res[i][pr] = *reinterpret_cast<const uint4*>((const bf16*)p.R + (mbase + i * 16) * 64 + pr * 32 + co_lane);
+    }
+    uint4 by[2][2];
+    unsigned bm[2][2];
+    if constexpr (STATS == 2) {   // the norm's input rows and ReLU bits of this tile, requested before its MFMAs
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          by[i][pr] = *reinterpret_cast<const uint4*>(p.bnr_y + (mbase + i * 16) * 64 + pr * 32 + co_lane);
+          bm[i][pr] = p.bnr_mask ? p.bnr_mask[(mbase + i * 16) * 8 + ((pr * 32 + co_lane) >> 3)] : 0xffu;
+        }
     }
 
     const char* patch = patch0 + buf * L1_PATCH_BYTES;
@@ -255,11 +270,12 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>((bf16*)p.C + (mbase + i * 16) * 64 + pr * 32 + co_lane) = o;
-        if constexpr (STATS) rvit_stat_acc8(o, st1[pr], st2[pr]);
+        if constexpr (STATS == 1) rvit_stat_acc8(o, st1[pr], st2[pr]);
+        if constexpr (STATS == 2) rvit_bnr_acc8(o, by[i][pr], bm[i][pr], bmean[pr], st1[pr], st2[pr]);
       }
     }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS != 0) {
     // batch statistics of everything this workgroup stored (GemmArgs::stat_part; the conv of a conv -> BatchNorm pair in
     // a training step): the sixteen pixel lanes of a lane row on the vector ALU, the seven compute waves through LDS in
     // wave order, one slot per workgroup.  The producer wave has left: the barriers below count the compute waves only.
@@ -288,6 +304,7 @@ __global__ __launch_bounds__(64 * L1_WAVES, 2) void conv3x3_c64_kernel(const Gem
       float tot = 0.f;
 #pragma unroll
       for (int w_ = 0; w_ < L1_CWAVES; ++w_) tot += sred[w_ * 128 + t];
+      if (STATS == 2 && t >= 64) tot *= rvit_bnr_rstd(p.bnr_fsums, 64, t - 64, p.bnr_inv_m, p.bnr_eps);
       p.stat_part[(long)blockIdx.x * 128 + t] = tot;
     }
   }
@@ -310,11 +327,17 @@ static int c64_launch(const GemmArgs& a, int n_cu, hipStream_t st) {
   if (const int rc = lim.ensure({(const void*)conv3x3_c64_kernel<HAS_R, RELU, AFFINE>}, L1_LDS, "conv3x3_c64")) return rc;
   const long ntiles = a.M / L1_TILE;
   const int grid = (int)(ntiles < n_cu ? ntiles : n_cu);
-  if constexpr (!HAS_R && !RELU && !AFFINE) {
-    if (rvit_conv_stats_wanted(a, grid)) {   // one slot per workgroup
+  if constexpr (!RELU && !AFFINE) {
+    const int smode = rvit_conv_stat_mode(a, grid);   // one slot per workgroup
+    if (smode != 0) {
       static RvitLdsLimit lim_s;
-      if (const int rc = lim_s.ensure({(const void*)conv3x3_c64_kernel<false, false, false, true>}, L1_LDS, "conv3x3_c64")) return rc;
-      hipLaunchKernelGGL((conv3x3_c64_kernel<false, false, false, true>), dim3(grid), dim3(64 * L1_WAVES), L1_LDS, st, a, (int)ntiles, a.H / L1_ROWS);
+      if (const int rc = lim_s.ensure({(const void*)conv3x3_c64_kernel<HAS_R, false, false, 1>,
+                                       (const void*)conv3x3_c64_kernel<HAS_R, false, false, 2>}, L1_LDS, "conv3x3_c64"))
+        return rc;
+      if (smode == 1)
+        hipLaunchKernelGGL((conv3x3_c64_kernel<HAS_R, false, false, 1>), dim3(grid), dim3(64 * L1_WAVES), L1_LDS, st, a, (int)ntiles, a.H / L1_ROWS);
+      else
+        hipLaunchKernelGGL((conv3x3_c64_kernel<HAS_R, false, false, 2>), dim3(grid), dim3(64 * L1_WAVES), L1_LDS, st, a, (int)ntiles, a.H / L1_ROWS);
       RVIT_CHECK_LAUNCH("conv3x3_c64");
       *a.stat_slots = grid;
       return RVIT_OK;

@@ -66,7 +66,7 @@ __device__ __forceinline__ int c8_fdiv(int m, int d, float inv_d) {
 constexpr int C8_MF = 7;        // pixel fragments per wave
 constexpr int C8_DUMMY = 8192;  // one dummy DMA slot per wave
 
-template <int TN, bool STATS = false>
+template <int TN, int STATS = 0>
 __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const int patch_bytes, const int tile_len,
                                                           const int ppw) {
   constexpr int WC = TN / 64;            // wave columns (64 channels each)
@@ -303,8 +303,30 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
   for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { st1[pr][e] = 0.f; st2[pr][e] = 0.f; }
+  // STATS 2 (GemmArgs::bnr_y): the norm's input rows and ReLU bits travel one fragment row ahead of their use, with the
+  // residual rows (all rows up front as below would not fit beside them)
+  float bmean[2][8];
+  uint4 nr[2], ny[2];
+  unsigned nm[2];
+  auto bnr_load = [&](int i0) {
+    int mr = mw0 + i0 * 16 + fr;
+    if (mr > m_last) mr = m_last;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      if (has_r) nr[pr] = *reinterpret_cast<const uint4*>((const bf16*)p.R + (long)mr * p.ldr + nl[pr]);
+      ny[pr] = *reinterpret_cast<const uint4*>(p.bnr_y + (long)mr * p.N + nl[pr]);
+      nm[pr] = p.bnr_mask ? p.bnr_mask[(long)mr * (p.N >> 3) + (nl[pr] >> 3)] : 0xffu;
+    }
+  };
+  if constexpr (STATS == 2) {
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bmean[pr][e] = p.bnr_fsums[nl[pr] + e] * p.bnr_inv_m;
+    bnr_load(0);
+  }
   uint4 rr[C8_MF][2];
-  if (has_r) {
+  if (has_r && STATS != 2) {
 #pragma unroll
     for (int i0 = 0; i0 < C8_MF; ++i0) {
       int mr = mw0 + i0 * 16 + fr;
@@ -316,6 +338,13 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
 #pragma unroll
   for (int i0 = 0; i0 < C8_MF; ++i0) {
     const int m = mw0 + i0 * 16 + fr;
+    uint4 cr[2], cy[2];
+    unsigned cm[2];
+    if constexpr (STATS == 2) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) { cr[pr] = nr[pr]; cy[pr] = ny[pr]; cm[pr] = nm[pr]; }
+      if (i0 + 1 < C8_MF) bnr_load(i0 + 1);
+    }
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       float v[8];
@@ -329,7 +358,7 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[pr][e] + bi[pr][e];
       if (has_r) {
-        const uint4 r = rr[i0][pr];
+        const uint4 r = STATS == 2 ? cr[pr] : rr[i0][pr];
         v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
         v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
       }
@@ -342,12 +371,13 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
         o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
         o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
         *reinterpret_cast<uint4*>((bf16*)p.C + (long)m * p.ldc + nl[pr]) = o;
-        if constexpr (STATS) rvit_stat_acc8(o, st1[pr], st2[pr]);
+        if constexpr (STATS == 1) rvit_stat_acc8(o, st1[pr], st2[pr]);
+        if constexpr (STATS == 2) rvit_bnr_acc8(o, cy[pr], cm[pr], bmean[pr], st1[pr], st2[pr]);
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of the (unused) tiles past the end must land before the LDS is released
-  if constexpr (STATS) {
+  if constexpr (STATS != 0) {
     // per-tile batch statistics (the conv of a conv -> BatchNorm pair in a training step, GemmArgs::stat_part): the
     // sixteen pixel lanes of a lane row on the vector ALU, then the wave rows of a column block through LDS in wave
     // order; one slot per M tile, fixed association, no atomics
@@ -376,7 +406,9 @@ __global__ __launch_bounds__(512) void conv3x3_p8_kernel(const GemmArgs p, const
       float tot = 0.f;
 #pragma unroll
       for (int w_ = 0; w_ < WR; ++w_) tot += sred[(w_ * WC + wc_) * 128 + q];
-      p.stat_part[(long)tile_m * 2 * p.N + (q >> 6) * p.N + n0 + wc_ * 64 + (q & 63)] = tot;
+      const int col = n0 + wc_ * 64 + (q & 63);
+      if (STATS == 2 && q >= 64) tot *= rvit_bnr_rstd(p.bnr_fsums, p.N, col, p.bnr_inv_m, p.bnr_eps);
+      p.stat_part[(long)tile_m * 2 * p.N + (q >> 6) * p.N + col] = tot;
     }
   }
 }
@@ -492,18 +524,19 @@ int rvit_conv3x3_p8(const GemmArgs& a, hipStream_t st) {
   if (pl.tiles <= 0) return RVIT_OK;
   RVIT_CHECK_ARG(pl.tiles < 0x7fffffffL, "conv3x3: too many tiles");
   const long mtiles = pl.tiles / (a.N / pl.tn);
-  const bool stats = rvit_conv_stats_wanted(a, mtiles);
+  const int stats = rvit_conv_stat_mode(a, mtiles);
   static RvitLdsLimit lim;
-  if (const int rc = lim.ensure({(const void*)conv3x3_p8_kernel<256, false>, (const void*)conv3x3_p8_kernel<128, false>,
-                                 (const void*)conv3x3_p8_kernel<256, true>, (const void*)conv3x3_p8_kernel<128, true>},
+  if (const int rc = lim.ensure({(const void*)conv3x3_p8_kernel<256, 0>, (const void*)conv3x3_p8_kernel<128, 0>,
+                                 (const void*)conv3x3_p8_kernel<256, 1>, (const void*)conv3x3_p8_kernel<128, 1>,
+                                 (const void*)conv3x3_p8_kernel<256, 2>, (const void*)conv3x3_p8_kernel<128, 2>},
                                 160 * 1024, "conv3x3_p8"))
     return rc;
 #define C8_LAUNCH(TN_, S_) \
   hipLaunchKernelGGL((conv3x3_p8_kernel<TN_, S_>), dim3((unsigned)pl.tiles), dim3(512), pl.lds, st, a, pl.patch_bytes, pl.tile_len, pl.ppw)
   if (pl.tn == 256) {
-    if (stats) C8_LAUNCH(256, true); else C8_LAUNCH(256, false);
+    if (stats == 1) C8_LAUNCH(256, 1); else if (stats == 2) C8_LAUNCH(256, 2); else C8_LAUNCH(256, 0);
   } else {
-    if (stats) C8_LAUNCH(128, true); else C8_LAUNCH(128, false);
+    if (stats == 1) C8_LAUNCH(128, 1); else if (stats == 2) C8_LAUNCH(128, 2); else C8_LAUNCH(128, 0);
   }
 #undef C8_LAUNCH
   RVIT_CHECK_LAUNCH("conv3x3_p8");

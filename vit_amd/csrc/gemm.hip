@@ -327,7 +327,8 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
   GemmArgs b = a;
   if (b.stat_part) {   // one statistics slot per M tile (this kernel's epilogue writes them)
     const long slots = (a.M + BM - 1) / BM;
-    if (a.vec && !a.c_f32 && a.row_group == 0 && slots <= a.stat_cap_slots && a.stat_slots) *a.stat_slots = (int)slots;
+    // (the BatchNorm backward sums, bnr_y, exist in the direct 3x3 kernels only: the caller runs rvit_bn_bwd_reduce)
+    if (!a.bnr_y && a.vec && !a.c_f32 && a.row_group == 0 && slots <= a.stat_cap_slots && a.stat_slots) *a.stat_slots = (int)slots;
     else b.stat_part = nullptr;
   }
   if (a.mode == 1)

@@ -234,8 +234,38 @@ __device__ __forceinline__ float rvit_sum_row16(float x) {
 // Does a conv launch with `slots` M tiles write the per-tile BatchNorm statistics (GemmArgs::stat_part)?  Only the plain
 // conv of a conv -> BatchNorm pair: no scale / bias / residual / activation, forward direction, slots within the workspace.
 static inline bool rvit_conv_stats_wanted(const GemmArgs& a, long slots) {
-  return a.stat_part && a.stat_slots && !a.scale && !a.bias && !a.R && a.act == RVIT_ACT_NONE && !a.transposed && slots > 0 &&
+  return a.stat_part && a.stat_slots && !a.bnr_y && !a.scale && !a.bias && !a.R && a.act == RVIT_ACT_NONE && !a.transposed &&
+         slots > 0 && slots <= a.stat_cap_slots;
+}
+// ... or the backward sums of the BatchNorm its output enters (GemmArgs::bnr_y)?  A residual is allowed (the gradient
+// arriving over the other branch of a block).
+static inline bool rvit_conv_bnr_wanted(const GemmArgs& a, long slots) {
+  return a.stat_part && a.stat_slots && a.bnr_y && a.bnr_fsums && !a.scale && !a.bias && a.act == RVIT_ACT_NONE && slots > 0 &&
          slots <= a.stat_cap_slots;
+}
+// 0 none, 1 forward statistics, 2 BatchNorm backward sums
+static inline int rvit_conv_stat_mode(const GemmArgs& a, long slots) {
+  return rvit_conv_stats_wanted(a, slots) ? 1 : rvit_conv_bnr_wanted(a, slots) ? 2 : 0;
+}
+
+// BatchNorm backward sums of 8 channels of one row: d = the stored gradient where the ReLU bit is set
+// (bn.hip bn_bwd_reduce_kernel's terms: s1 += d, s2 += d (y - mean); rstd is applied to the slot total)
+__device__ __forceinline__ void rvit_bnr_acc8(const uint4& o, const uint4& y, unsigned mask, const float (&mean)[8], float (&s1)[8],
+                                              float (&s2)[8]) {
+  const float d[8] = {bf16_lo(o.x), bf16_hi(o.x), bf16_lo(o.y), bf16_hi(o.y), bf16_lo(o.z), bf16_hi(o.z), bf16_lo(o.w), bf16_hi(o.w)};
+  const float v[8] = {bf16_lo(y.x), bf16_hi(y.x), bf16_lo(y.y), bf16_hi(y.y), bf16_lo(y.z), bf16_hi(y.z), bf16_lo(y.w), bf16_hi(y.w)};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float de = (mask >> e) & 1u ? d[e] : 0.f;
+    s1[e] += de;
+    s2[e] += de * (v[e] - mean[e]);
+  }
+}
+// rstd of channel c from the forward sums (as bn.hip computes it)
+__device__ __forceinline__ float rvit_bnr_rstd(const float* fsums, int C, int c, float inv_m, float eps) {
+  const float mean = fsums[c] * inv_m;
+  const float var = fmaxf(fsums[C + c] * inv_m - mean * mean, 0.f);
+  return 1.0f / sqrtf(var + eps);
 }
 
 // x summed over the eight lanes l ^ {0, 8, 16, 24, 32, 40, 48, 56} (every lane gets the total; fixed association):

@@ -47,6 +47,14 @@ struct GemmArgs {
   float* stat_part;
   long stat_cap_slots;
   int* stat_slots;
+  // ... or, for a dgrad conv whose output is the gradient entering a BatchNorm (+ ReLU) (rvit_conv2d_dgrad_bnr_bf16), the
+  // two sums of that norm's backward pass (bn.hip bn_bwd_reduce_kernel) over the rows of the tile, in the same slots:
+  // sum d | rstd * sum d (y - mean), d = stored bf16 output where the ReLU bit is set (bnr_mask null: everywhere).
+  // bnr_y: the norm's input map, [M, N] bf16; bnr_mask: one byte per 8 channels; bnr_fsums: the forward sums [2N].
+  const bf16* bnr_y;
+  const uint8_t* bnr_mask;
+  const float* bnr_fsums;
+  float bnr_inv_m, bnr_eps;
 };
 
 int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream);

@@ -1103,6 +1103,46 @@ def conv2d_dgrad(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: i
     return dx
 
 
+def conv2d_dgrad_bn_sums(dy: torch.Tensor, w_t: torch.Tensor, dx: torch.Tensor, *, kh: int, kw: int, stride: int, pad: int,
+                         bn_y: torch.Tensor, bn_relu_mask: Optional[torch.Tensor], bn_fwd_sums: torch.Tensor,
+                         bn_bwd_sums: torch.Tensor, eps: float, stat_ws: torch.Tensor,
+                         residual: Optional[torch.Tensor] = None) -> bool:
+    """conv2d_dgrad whose output dx enters the backward pass of a train-mode BatchNorm (+ ReLU): where the conv kernel has
+    the hook (direct 3x3 / stride 1 kernels) its epilogue also produces that norm's two backward sums
+    (bn_bwd_sums[0:C] += sum d, [C:2C] += rstd * sum d (y - mean), d = dx where the ReLU bit is set) and bn_bwd runs with
+    reduced=True afterwards.  Returns False where it does not: dx is complete, bn_bwd_sums untouched."""
+    _need_cuda(dy, w_t, dx, residual, bn_y, bn_relu_mask, bn_fwd_sums, bn_bwd_sums, stat_ws)
+    B, Hy, Wy, Cout = dy.shape
+    Bx, Hx, Wx, Cin = dx.shape
+    if Bx != B or w_t.shape != (Cin, kh * kw * Cout) or dy.dtype != BF16 or dx.dtype != BF16 or w_t.dtype != BF16 \
+            or not (dy.is_contiguous() and dx.is_contiguous() and w_t.is_contiguous()):
+        raise ValueError("conv2d_dgrad_bn_sums: bad operands")
+    if residual is not None and (residual.shape != dx.shape or residual.dtype != BF16 or not residual.is_contiguous()):
+        raise ValueError("conv2d_dgrad_bn_sums: residual must match dx")
+    if bn_y.shape != dx.shape or bn_y.dtype != BF16 or not bn_y.is_contiguous():
+        raise ValueError("conv2d_dgrad_bn_sums: bn_y must match dx")
+    _check_relu_mask(bn_relu_mask, B * Hx * Wx, Cin, bn_relu_mask is not None)
+    _vec_f32(bn_fwd_sums, 2 * Cin, "conv2d_dgrad_bn_sums: bn_fwd_sums")
+    _vec_f32(bn_bwd_sums, 2 * Cin, "conv2d_dgrad_bn_sums: bn_bwd_sums")
+    if stat_ws.dtype != torch.float32 or not stat_ws.is_contiguous() or stat_ws.numel() <= STAT_STAGE_FLOATS:
+        raise ValueError("conv2d_dgrad_bn_sums: stat_ws must come from ops.conv_stats_workspace()")
+    lib = _lib.load()
+    slots = ctypes.c_int(0)
+    slot_floats = stat_ws.numel() - STAT_STAGE_FLOATS
+    name = _conv3x3_name(B, Hx, Wx, Cout, Cin) if (kh == 3 and kw == 3 and stride == 1 and pad == 1) else "conv2d_dgrad"
+    with _Span(name, 2 * B * Hy * Wy * Cout * kh * kw * Cin, _nbytes(dy, w_t, dx, residual, bn_y)):
+        check(lib.rvit_conv2d_dgrad_bnr_bf16(dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), B, Hy, Wy, Cout, kh, kw, stride,
+                                             pad, Hx, Wx, Cin, _ptr(residual), bn_y.data_ptr(), _ptr(bn_relu_mask),
+                                             bn_fwd_sums.data_ptr(), eps, stat_ws.data_ptr(), slot_floats * 4,
+                                             ctypes.byref(slots), _stream()), "rvit_conv2d_dgrad_bnr_bf16")
+    if slots.value <= 0:
+        return False
+    with _Span("bn_stats_finalize", 0, slots.value * 2 * Cin * 4):
+        check(lib.rvit_bn_stats_finalize(stat_ws.data_ptr(), slots.value, Cin, bn_bwd_sums.data_ptr(),
+                                         stat_ws.data_ptr() + slot_floats * 4, _stream()), "rvit_bn_stats_finalize")
+    return True
+
+
 S2_TAP_ORDER = (4, 5, 3, 7, 1, 8, 6, 2, 0)   # K-block order of the w_s2 pack (include/rvit.h)
 
 
@@ -1344,10 +1384,12 @@ def _check_relu_mask(mask, M, C, relu):
 def bn_bwd(dz: torch.Tensor, z: Optional[torch.Tensor], y: torch.Tensor, fwd_sums: torch.Tensor,
            bwd_sums: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, *,
            eps: float, relu: bool, dz_masked: Optional[torch.Tensor] = None,
-           relu_mask: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+           relu_mask: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None,
+           reduced: bool = False) -> torch.Tensor:
     """Both BatchNorm backward passes (reduce, then apply); bwd_sums must be zero on entry.  With relu the sign of
     the forward output comes from `relu_mask` (the bits `bn_apply` wrote) when given, else from z.  workspace
-    (ops.bn_workspace): ordered reduction, as in bn_stats."""
+    (ops.bn_workspace): ordered reduction, as in bn_stats.  reduced: bwd_sums already hold the two sums (the conv that
+    produced dz wrote them, conv2d_dgrad_bn_sums): only the apply pass runs."""
     _need_cuda(dz, z, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, dz_masked, relu_mask, workspace)
     _check_bn_ws(workspace)
     M, C = _map2d(y, "bn_bwd y")
@@ -1361,9 +1403,10 @@ def bn_bwd(dz: torch.Tensor, z: Optional[torch.Tensor], y: torch.Tensor, fwd_sum
     for v, n in ((fwd_sums, 2 * C), (bwd_sums, 2 * C), (gamma, C), (dgamma, C), (dbeta, C)):
         _vec_f32(v, n, "bn_bwd: vector")
     lib = _lib.load()
-    with _Span("bn_bwd_reduce", 0, _nbytes(dz, y, z if relu else None)):
-        check(lib.rvit_bn_bwd_reduce(dz.data_ptr(), _ptr(zsrc), y.data_ptr(), fwd_sums.data_ptr(), M, C, eps, mode,
-                                     bwd_sums.data_ptr(), _ptr(workspace), _stream()), "rvit_bn_bwd_reduce")
+    if not reduced:
+        with _Span("bn_bwd_reduce", 0, _nbytes(dz, y, z if relu else None)):
+            check(lib.rvit_bn_bwd_reduce(dz.data_ptr(), _ptr(zsrc), y.data_ptr(), fwd_sums.data_ptr(), M, C, eps, mode,
+                                         bwd_sums.data_ptr(), _ptr(workspace), _stream()), "rvit_bn_bwd_reduce")
     with _Span("bn_bwd_apply", 0, _nbytes(dz, y, zsrc if relu else None, dy, dz_masked)):
         check(lib.rvit_bn_bwd_apply(dz.data_ptr(), _ptr(zsrc), y.data_ptr(), fwd_sums.data_ptr(), bwd_sums.data_ptr(),
                                     gamma.data_ptr(), dy.data_ptr(), _ptr(dz_masked), dgamma.data_ptr(),

@@ -253,6 +253,9 @@ class TrainEngine:
         self.conv1_roll = os.environ.get("RVIT_CONV1_TRAIN_ROLL", "1") != "0"
         # ... and its weight gradient on the same band (ordered slots only; 0: implicit GEMM on the packed copy)
         self.conv1_wgrad_roll = os.environ.get("RVIT_CONV1_WGRAD_ROLL", "1") != "0"
+        # BatchNorm backward sums in the epilogue of the dgrad conv that produces the norm's incoming gradient (0: the
+        # bn_bwd_reduce pass, A/B runs)
+        self.bnr_fused = os.environ.get("RVIT_BN_REDUCE_FUSED", "1") != "0"
         self.mb = None   # MobileStemTrainer for backbone='mobilenetv3'
         if getattr(model, "backbone_name", None) == "mobilenetv3":
             from .mobile_trainer import MobileStemTrainer
@@ -559,9 +562,12 @@ class TrainEngine:
         bs_all, fs_all = b["bsums"], b["fsums"]
         ws = b["bn_ws"] if self.ordered_bn else None
         dz = dfeat
+        dz_reduced = False   # the conv that produced dz already wrote the sums of the norm it enters
+        sws = self._stat_ws(dfeat.device)
         blocks = list(zip(list(cb.blocks()), P["blocks"], b["blocks"],
                           [n for n in self._block_names()]))
-        for blk, pk, d, pref in reversed(blocks):
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk, pk, d, pref = blocks[bi]
             s, co, ci = pk["stride"], pk["cout"], pk["cin"]
             off = d["fs_off"]
             has_ds = "ds_w" in pk
@@ -574,15 +580,23 @@ class TrainEngine:
             dzm = self._scratch(b, ("dzm", co, d["y2"].shape[1]), d["y2"])
             ops.bn_bwd(dz, None, d["y2"], f2, b2, blk.bn2.weight.detach(), dy2,
                        self._g(flat, pref + "bn2.weight"), self._g(flat, pref + "bn2.bias"), eps=blk.bn2.eps, relu=True,
-                       dz_masked=dzm, relu_mask=d["mo"], workspace=ws)
+                       dz_masked=dzm, relu_mask=d["mo"], workspace=ws, reduced=dz_reduced)
+            dz_reduced = False
             ops.conv2d_wgrad(dy2, d["z1"], self._g(flat, pref + "conv2.weight").view(co, 9 * co), kh=3, kw=3, stride=1,
                              pad=1)
             dz1 = self._scratch(b, ("dz1", co, d["y2"].shape[1]), d["y2"])
-            ops.conv2d_dgrad(dy2, pk["c2_wt"], dz1, kh=3, kw=3, stride=1, pad=1)
+            red1 = False
+            if self.bnr_fused:
+                # dz1 enters bn1's backward pass: its two sums come out of this conv's epilogue
+                red1 = ops.conv2d_dgrad_bn_sums(dy2, pk["c2_wt"], dz1, kh=3, kw=3, stride=1, pad=1, bn_y=d["y1"],
+                                                bn_relu_mask=d["m1"], bn_fwd_sums=f1, bn_bwd_sums=b1, eps=blk.bn1.eps,
+                                                stat_ws=sws)
+            else:
+                ops.conv2d_dgrad(dy2, pk["c2_wt"], dz1, kh=3, kw=3, stride=1, pad=1)
             dy1 = dy2  # dy2 is dead now
             ops.bn_bwd(dz1, None, d["y1"], f1, b1, blk.bn1.weight.detach(), dy1,
                        self._g(flat, pref + "bn1.weight"), self._g(flat, pref + "bn1.bias"), eps=blk.bn1.eps, relu=True,
-                       relu_mask=d["m1"], workspace=ws)
+                       relu_mask=d["m1"], workspace=ws, reduced=red1)
             xin = d["in"]
             ops.conv2d_wgrad(dy1, xin, self._g(flat, pref + "conv1.weight").view(co, 9 * ci), kh=3, kw=3, stride=s,
                              pad=1)
@@ -602,6 +616,15 @@ class TrainEngine:
                     tmp = self._scratch(b, ("dxt", ci, xin.shape[1]), xin)
                     ops.conv2d_dgrad(dyd, pk["ds_wt"], tmp, kh=1, kw=1, stride=s, pad=0)
                     ops.conv2d_dgrad(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=s, pad=1, residual=tmp)
+            elif self.bnr_fused and bi > 0 and s == 1:
+                # dxin enters bn2 of the block before this one
+                pblk, ppk, pd, _ = blocks[bi - 1]
+                poff, pco = pd["fs_off"], ppk["cout"]
+                dz_reduced = ops.conv2d_dgrad_bn_sums(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=1, pad=1, residual=dzm,
+                                                      bn_y=pd["y2"], bn_relu_mask=pd["mo"],
+                                                      bn_fwd_sums=fs_all[poff + 2 * pco:poff + 4 * pco],
+                                                      bn_bwd_sums=bs_all[poff + 2 * pco:poff + 4 * pco],
+                                                      eps=pblk.bn2.eps, stat_ws=sws)
             else:
                 ops.conv2d_dgrad(dy1, pk["c1_wt"], dxin, kh=3, kw=3, stride=s, pad=1, residual=dzm)
             dz = dxin
