@@ -569,12 +569,15 @@ def test_bn_apply_pool_fused(dev, B, H, W, C):
     assert (p.float().cpu() - pr).abs().max().item() <= 2.0 ** -7 * max(1.0, pr.abs().max().item())
 
 
-@pytest.mark.parametrize("B,H,W,C", [(3, 112, 112, 64), (2, 15, 9, 64), (5, 8, 8, 128), (1, 7, 30, 16)])
+@pytest.mark.parametrize("B,H,W,C", [(3, 112, 112, 64), (2, 15, 9, 64), (5, 8, 8, 128), (1, 7, 30, 16), (2, 2, 2, 64),
+                                     (7, 6, 20, 32)])
 @pytest.mark.parametrize("ordered", [False, True])
 def test_bn_bwd_behind_maxpool_fused(dev, B, H, W, C, ordered):
     """bn_bwd_pool (the max-pool's gradient gathered inside the two BatchNorm backward passes) against
-    maxpool3x3s2_bwd + bn_bwd(relu_mask=...): dy bit-identical; the sums bit-identical with the ordered reductions
-    (the atomic form differs in its arrival order from run to run).  Odd sizes: clipped windows, rows in one window only."""
+    maxpool3x3s2_bwd + bn_bwd(relu_mask=...).  Given the same two sums, dy is bit-identical (the gathered gradient of a
+    pixel is the value maxpool_bwd stores).  The sums themselves: bit-identical with the ordered reductions on odd maps
+    (per-pixel kernels, bn_bwd's partition); on even maps the passes walk 2 x 2 pixel blocks and add in another order:
+    equal to fp32 round-off, identical from run to run.  Odd sizes: clipped windows, rows in one window only."""
     from vit_amd import ops
     g = torch.Generator().manual_seed(B * H + W + C)
     y = (torch.randn(B, H, W, C, generator=g) * 1.3 - 0.1).bfloat16().to(dev)
@@ -598,9 +601,22 @@ def test_bn_bwd_behind_maxpool_fused(dev, B, H, W, C, ordered):
     bs2, dg2, db2 = torch.zeros(2 * C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     dy2 = torch.full_like(y, float("nan"))
     ops.bn_bwd_pool(dpool, arg, mask, y, fs, bs2, gamma, dy2, dg2, db2, eps=1e-5, workspace=ws)
-    if ordered:
+    # the apply pass alone on bn_bwd's sums: the same bits
+    dy3 = torch.full_like(y, float("nan"))
+    ops.bn_bwd_pool(dpool, arg, mask, y, fs, bs1.clone(), gamma, dy3, torch.zeros(C, device=dev), torch.zeros(C, device=dev),
+                    eps=1e-5, reduced=True)
+    assert torch.equal(dy1, dy3)
+    if ordered and ((H | W) & 1):
         assert torch.equal(bs1, bs2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
         assert torch.equal(dy1, dy2)
+    elif ordered:
+        bs3 = torch.zeros(2 * C, device=dev)
+        ops.bn_bwd_pool(dpool, arg, mask, y, fs, bs3, gamma, torch.empty_like(y), torch.zeros(C, device=dev),
+                        torch.zeros(C, device=dev), eps=1e-5, workspace=ws)
+        assert torch.equal(bs2, bs3)
+        scale = max(1.0, bs1.abs().max().item())
+        assert (bs1 - bs2).abs().max().item() <= 2e-5 * scale * math.sqrt(B * H * W)
+        assert (dy1.float() - dy2.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, dy1.float().abs().max().item())
     else:
         assert torch.allclose(bs1, bs2, rtol=1e-4, atol=1e-3)
         assert (dy1.float() - dy2.float()).abs().max().item() <= 2e-2 * max(1.0, dy1.float().abs().max().item())

@@ -9,6 +9,7 @@
 //                                                              running_mean / running_var)
 //   backward: dzm = dz * (z > 0);  bs[c] = (sum dzm, sum dzm*xhat)          (bn_bwd_reduce)
 //             dy = gamma*rstd*(dzm - bs1/M - xhat*bs2/M); dgamma += bs2; dbeta += bs1  (bn_bwd_apply)
+#include <stdlib.h>
 #include "common.h"
 #include "rvit_internal.h"
 
@@ -37,6 +38,9 @@ __device__ __forceinline__ unsigned mask8(const uint4 o) {
   }
   return m;
 }
+// dy = a * dzm + b * y + c with the two roundings written out (explicit fused multiply-adds): every kernel that applies
+// it gives the same bits, whatever the compiler would have contracted in its context
+__device__ __forceinline__ float bn_dy(float a, float d, float b, float y, float c) { return __fmaf_rn(a, d, __fmaf_rn(b, y, c)); }
 __device__ __forceinline__ void apply_mask8(float (&d)[8], unsigned m) {
 #pragma unroll
   for (int k = 0; k < 8; ++k) d[k] = (m >> k) & 1u ? d[k] : 0.f;
@@ -574,7 +578,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
       if (relu == 2) apply_mask8(d, mu[j]);
       if (dzm_out) *reinterpret_cast<uint4*>(dzm_out + o) = pack8(d);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) out[k] = ca[k] * d[k] + cb[k] * yv[k] + cc[k];
+      for (int k = 0; k < 8; ++k) out[k] = bn_dy(ca[k], d[k], cb[k], yv[k], cc[k]);
       *reinterpret_cast<uint4*>(dy + o) = pack8(out);
     }
   }
@@ -593,8 +597,163 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
     if (relu == 2) apply_mask8(d, zmask[m * cpr + s.chunk]);
     if (dzm_out) *reinterpret_cast<uint4*>(dzm_out + o) = pack8(d);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) out[k] = ca[k] * d[k] + cb[k] * yv[k] + cc[k];
+    for (int k = 0; k < 8; ++k) out[k] = bn_dy(ca[k], d[k], cb[k], yv[k], cc[k]);
     *reinterpret_cast<uint4*>(dy + o) = pack8(out);
+  }
+}
+
+// ---- the same two passes by 2 x 2 pixel blocks (H and W even: the stem's 112 x 112 map) -------------------------------------
+// The four pixels (2i + di, 2j + dj) draw on the same four pooled positions (i + a, j + c): one thread fetches those four
+// gradient chunks and tap records once and forms the four gathered gradients from them - 16 memory requests per four
+// pixels where the per-pixel form issues 40 (it was bound by request rate: 238 / 285 us at B = 256 for 0.62 / 1.03 GB).
+// Every pixel's value is the sum maxpool_bwd_kernel forms, in its (kh, kw) order, rounded to bf16: same bits per pixel.
+struct PoolBlock { long pix[4]; };   // row index (pixel) of (2i, 2j), (2i, 2j+1), (2i+1, 2j), (2i+1, 2j+1)
+__device__ __forceinline__ PoolBlock pool_block_grad(const bf16* __restrict__ dpool, const PoolGeom& g, long mb, int C, int c0,
+                                                      float (&d)[4][8]) {
+  const int hb = g.H >> 1, wb = g.W >> 1, bhw = hb * wb, mi = (int)mb;
+  int b = (int)((float)mi * g.r_hw * 4.0f);
+  int rem = mi - b * bhw;
+  if (rem < 0) { --b; rem += bhw; } else if (rem >= bhw) { ++b; rem -= bhw; }
+  int i = (int)((float)rem * g.r_w * 2.0f);
+  int j = rem - i * wb;
+  if (j < 0) { --i; j += wb; } else if (j >= wb) { ++i; j -= wb; }
+  const bool hB = i + 1 < g.Ho, wB = j + 1 < g.Wo;
+  const int i1 = hB ? i + 1 : i, j1 = wB ? j + 1 : j;
+  const long prow0 = ((long)b * g.Ho + i) * g.Wo, prow1 = ((long)b * g.Ho + i1) * g.Wo;
+  const long po[4] = {(prow0 + j) * C + c0, (prow0 + j1) * C + c0, (prow1 + j) * C + c0, (prow1 + j1) * C + c0};
+  uint4 dv[4];
+  uint2 am[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    dv[q] = *reinterpret_cast<const uint4*>(dpool + po[q]);
+    am[q] = *reinterpret_cast<const uint2*>(g.argmax + po[q]);
+  }
+  float v[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) unpack8(dv[q], v[q]);
+  // (pooled position, tap) pairs of each pixel in (kh, kw) order; a pooled position that does not exist never matches
+  const int t01 = wB ? 3 : 64, t10 = hB ? 1 : 64, t11 = (hB && wB) ? 0 : 64, t10b = hB ? 2 : 64, t01b = wB ? 6 : 64;
+  float acc[4][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = (int)(((k < 4 ? am[q].x : am[q].y) >> (8 * (k & 3))) & 0xff);
+    float s;
+    s = 0.f; if (a[0] == 4) s += v[0][k];
+    acc[0][k] = s;
+    s = 0.f; if (a[1] == t01) s += v[1][k]; if (a[0] == 5) s += v[0][k];
+    acc[1][k] = s;
+    s = 0.f; if (a[2] == t10) s += v[2][k]; if (a[0] == 7) s += v[0][k];
+    acc[2][k] = s;
+    s = 0.f; if (a[3] == t11) s += v[3][k]; if (a[2] == t10b) s += v[2][k]; if (a[1] == t01b) s += v[1][k]; if (a[0] == 8) s += v[0][k];
+    acc[3][k] = s;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) unpack8(pack8(acc[q]), d[q]);   // the bf16 rounding of the stored map
+  PoolBlock pb;
+  const long r0 = ((long)b * g.H + 2 * i) * g.W + 2 * j;
+  pb.pix[0] = r0; pb.pix[1] = r0 + 1; pb.pix[2] = r0 + g.W; pb.pix[3] = r0 + g.W + 1;
+  return pb;
+}
+
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_reduce_pool2_kernel(const bf16* __restrict__ dpool,
+                                                                          const uint8_t* __restrict__ zmask,
+                                                                          const bf16* __restrict__ y,
+                                                                          const float* __restrict__ fsums, long MB, int C,
+                                                                          float eps, float* __restrict__ bsums,
+                                                                          float* __restrict__ ws, const PoolGeom pg) {
+  extern __shared__ float red[];
+  if (!ws) {
+    for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) red[i] = 0.f;
+    __syncthreads();
+  }
+  const RowSpan s = row_span(MB, C, RED_THREADS);
+  const int c0 = s.chunk * 8, cpr = C >> 3;
+  const float inv_m = 0.25f / (float)MB;
+  float mean[8], s1[8], s2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    mean[k] = fsums[c0 + k] * inv_m;
+    s1[k] = 0.f; s2[k] = 0.f;
+  }
+  for (long m = s.m0 + s.r; m < s.m1; m += s.rows_per_pass) {
+    float d[4][8];
+    const PoolBlock pb = pool_block_grad(dpool, pg, m, C, c0, d);
+    uint4 yu[4];
+    unsigned mu[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      yu[q] = *reinterpret_cast<const uint4*>(y + pb.pix[q] * C + c0);
+      mu[q] = zmask[pb.pix[q] * cpr + s.chunk];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float yv[8];
+      unpack8(yu[q], yv);
+      apply_mask8(d[q], mu[q]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s1[k] += d[q][k]; s2[k] += d[q][k] * (yv[k] - mean[k]); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float var = fmaxf(fsums[C + c0 + k] * inv_m - mean[k] * mean[k], 0.f);
+    s2[k] *= 1.0f / sqrtf(var + eps);
+  }
+  if (ws) {
+    red_commit_det(red, C, s.chunk, s1, s2, ws, bsums);
+    return;
+  }
+  red_commit(red, C, s.chunk, s1, s2);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += RED_THREADS) atomicAdd(bsums + i, red[i]);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool2_kernel(const bf16* __restrict__ dpool, const uint8_t* __restrict__ zmask,
+                                                                 const bf16* __restrict__ y, const float* __restrict__ fsums,
+                                                                 const float* __restrict__ bsums,
+                                                                 const float* __restrict__ gamma, bf16* __restrict__ dy,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, long MB,
+                                                                 int C, float eps, const PoolGeom pg) {
+  const RowSpan s = row_span(MB, C);
+  const int c0 = s.chunk * 8, cpr = C >> 3;
+  const float inv_m = 0.25f / (float)MB;
+  float ca[8], cb[8], cc[8];   // dy = a*dzm + b*y + c, as bn_bwd_apply_kernel
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + k;
+    const float mean = fsums[c] * inv_m;
+    const float var = fmaxf(fsums[C + c] * inv_m - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float b1 = bsums[c], b2 = bsums[C + c];
+    ca[k] = gamma[c] * rstd;
+    cb[k] = -ca[k] * rstd * b2 * inv_m;
+    cc[k] = -ca[k] * b1 * inv_m - cb[k] * mean;
+    if (blockIdx.x == 0 && s.r == 0) {  // one thread per channel
+      dgamma[c] += b2;
+      dbeta[c] += b1;
+    }
+  }
+  for (long m = s.m0 + s.r; m < s.m1; m += s.rows_per_pass) {
+    float d[4][8];
+    const PoolBlock pb = pool_block_grad(dpool, pg, m, C, c0, d);
+    uint4 yu[4];
+    unsigned mu[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      yu[q] = *reinterpret_cast<const uint4*>(y + pb.pix[q] * C + c0);
+      mu[q] = zmask[pb.pix[q] * cpr + s.chunk];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float yv[8], out[8];
+      unpack8(yu[q], yv);
+      apply_mask8(d[q], mu[q]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) out[k] = bn_dy(ca[k], d[q][k], cb[k], yv[k], cc[k]);
+      *reinterpret_cast<uint4*>(dy + pb.pix[q] * C + c0) = pack8(out);
+    }
   }
 }
 
@@ -737,6 +896,11 @@ int rvit_bn_bwd_apply_impl(const void* dz, const void* z, const void* y, const f
 
 // BatchNorm backward behind a 3x3 / stride-2 max-pool (the stem's bn1 -> relu -> maxpool, train_vit.py:145 through timm's
 // resnet): rvit_maxpool3x3s2_bwd_nhwc + rvit_bn_bwd_reduce / rvit_bn_bwd_apply (relu = 2) without the un-pooled gradient map
+// RVIT_POOL_BWD_PER_PIXEL=1: the per-pixel kernels also on even maps (A/B runs; same bits per pixel of dy given equal sums)
+static bool pool_per_pixel() {
+  static const bool v = [] { const char* e = getenv("RVIT_POOL_BWD_PER_PIXEL"); return e && e[0] == '1'; }();
+  return v;
+}
 static int pool_geom(const void* argmax, int B, int H, int W, int C, PoolGeom* g, const char* what) {
   RVIT_CHECK_ARG(B > 0 && H > 1 && W > 1 && (long)B * H * W < (1L << 24), "%s: B*H*W must be below 2^24", what);
   RVIT_CHECK_ARG(argmax && (((uintptr_t)argmax) & 7) == 0, "%s: argmax alignment", what);
@@ -755,6 +919,13 @@ int rvit_bn_bwd_reduce_pool_impl(const void* dpool, const void* argmax, const vo
   RVIT_CHECK_ARG(rvit_aligned16(dpool) && rvit_aligned16(y), "bn_bwd_reduce_pool: alignment");
   PoolGeom g;
   if (const int rc = pool_geom(argmax, B, H, W, C, &g, "bn_bwd_reduce_pool")) return rc;
+  if (!(H & 1) && !(W & 1) && !pool_per_pixel()) {   // by 2 x 2 pixel blocks
+    const long MB = M / 4, blocks = red_blocks(MB, C, ws != nullptr);
+    hipLaunchKernelGGL(bn_bwd_reduce_pool2_kernel, dim3((unsigned)blocks), dim3(RED_THREADS), red_lds(C, ws != nullptr), st,
+                       (const bf16*)dpool, (const uint8_t*)relu_mask, (const bf16*)y, fsums, MB, C, eps, bsums, ws, g);
+    RVIT_CHECK_LAUNCH("bn_bwd_reduce_pool");
+    return RVIT_OK;
+  }
   const long blocks = red_blocks(M, C, ws != nullptr);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3((unsigned)blocks), dim3(RED_THREADS), red_lds(C, ws != nullptr), st,
                      (const bf16*)dpool, (const bf16*)relu_mask, (const bf16*)y, fsums, M, C, eps, 2, bsums, ws, g);
@@ -771,6 +942,13 @@ int rvit_bn_bwd_apply_pool_impl(const void* dpool, const void* argmax, const voi
   RVIT_CHECK_ARG(rvit_aligned16(dpool) && rvit_aligned16(y) && rvit_aligned16(dy), "bn_bwd_apply_pool: alignment");
   PoolGeom g;
   if (const int rc = pool_geom(argmax, B, H, W, C, &g, "bn_bwd_apply_pool")) return rc;
+  if (!(H & 1) && !(W & 1) && !pool_per_pixel()) {
+    const long MB = M / 4, blocks = bn_blocks(MB, C, 4);
+    hipLaunchKernelGGL(bn_bwd_apply_pool2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dpool,
+                       (const uint8_t*)relu_mask, (const bf16*)y, fsums, bsums, gamma, (bf16*)dy, dgamma, dbeta, MB, C, eps, g);
+    RVIT_CHECK_LAUNCH("bn_bwd_apply_pool");
+    return RVIT_OK;
+  }
   const long blocks = bn_blocks(M, C, 8);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dpool,
                      (const bf16*)relu_mask, (const bf16*)y, fsums, bsums, gamma, (bf16*)dy, (bf16*)nullptr, dgamma, dbeta,

@@ -63,8 +63,17 @@ __global__ __launch_bounds__(256) void ordered_finalize_wide_kernel(const float*
   const int c = ok ? (int)(o - r * cols) : 0;
   const float* src = part + r * cols + c;
   float t = 0.f;
-  if (ok)
-    for (int s = g; s < nslots; s += G) t += src[(long)s * slot_stride];
+  if (ok) {
+    int s = g;
+    for (; s + 7 * G < nslots; s += 8 * G) {   // eight loads in flight; the additions stay in slot order
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + (long)(s + j * G) * slot_stride);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t += v[j];
+    }
+    for (; s < nslots; s += G) t += __builtin_nontemporal_load(src + (long)s * slot_stride);
+  }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
   if (ok && g == 0) out[r * ld + c] += t;

@@ -1417,10 +1417,12 @@ def bn_bwd(dz: torch.Tensor, z: Optional[torch.Tensor], y: torch.Tensor, fwd_sum
 def bn_bwd_pool(dpool: torch.Tensor, argmax: torch.Tensor, relu_mask: torch.Tensor, y: torch.Tensor,
                 fwd_sums: torch.Tensor, bwd_sums: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor,
                 dgamma: torch.Tensor, dbeta: torch.Tensor, *, eps: float,
-                workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+                workspace: Optional[torch.Tensor] = None, reduced: bool = False) -> torch.Tensor:
     """maxpool3x3s2_bwd + bn_bwd(relu=True, relu_mask=...) in two launches instead of three: the un-pooled gradient
-    map is gathered inside the two BatchNorm passes instead of being written and read twice (same bits).
-    dpool / argmax [B,Ho,Wo,C], y / dy [B,H,W,C], relu_mask the bits bn_apply_pool wrote; bwd_sums zero on entry."""
+    map is gathered inside the two BatchNorm passes instead of being written and read twice (the same gradient bits per
+    pixel; on even maps the passes walk 2 x 2 pixel blocks, so the two sums are added in another order than bn_bwd's).
+    dpool / argmax [B,Ho,Wo,C], y / dy [B,H,W,C], relu_mask the bits bn_apply_pool wrote; bwd_sums zero on entry
+    (reduced: they already hold the two sums, only the apply pass runs)."""
     _need_cuda(dpool, argmax, relu_mask, y, fwd_sums, bwd_sums, gamma, dy, dgamma, dbeta, workspace)
     _check_bn_ws(workspace)
     if y.dim() != 4:
@@ -1435,10 +1437,11 @@ def bn_bwd_pool(dpool: torch.Tensor, argmax: torch.Tensor, relu_mask: torch.Tens
     for v, n in ((fwd_sums, 2 * C), (bwd_sums, 2 * C), (gamma, C), (dgamma, C), (dbeta, C)):
         _vec_f32(v, n, "bn_bwd_pool: vector")
     lib = _lib.load()
-    with _Span("bn_bwd_reduce", 0, _nbytes(dpool, argmax, y, relu_mask)):
-        check(lib.rvit_bn_bwd_reduce_pool(dpool.data_ptr(), argmax.data_ptr(), relu_mask.data_ptr(), y.data_ptr(),
-                                          fwd_sums.data_ptr(), B, H, W, C, eps, bwd_sums.data_ptr(), _ptr(workspace),
-                                          _stream()), "rvit_bn_bwd_reduce_pool")
+    if not reduced:
+        with _Span("bn_bwd_reduce", 0, _nbytes(dpool, argmax, y, relu_mask)):
+            check(lib.rvit_bn_bwd_reduce_pool(dpool.data_ptr(), argmax.data_ptr(), relu_mask.data_ptr(), y.data_ptr(),
+                                              fwd_sums.data_ptr(), B, H, W, C, eps, bwd_sums.data_ptr(), _ptr(workspace),
+                                              _stream()), "rvit_bn_bwd_reduce_pool")
     with _Span("bn_bwd_apply", 0, _nbytes(dpool, argmax, y, relu_mask, dy)):
         check(lib.rvit_bn_bwd_apply_pool(dpool.data_ptr(), argmax.data_ptr(), relu_mask.data_ptr(), y.data_ptr(),
                                          fwd_sums.data_ptr(), bwd_sums.data_ptr(), gamma.data_ptr(), dy.data_ptr(),
