@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void ordered_finalize_kernel(const float* __re
 // 256 slots): G lanes per output, lane g adds slots g, g + G, ... in order, then the fixed xor butterfly over the G
 // lanes: still one association on every run, without a slots-deep dependent chain in one thread.
 template <int G>
-__global__ __launch_bounds__(256) void ordered_finalize_wide_kernel(const float* __restrict__ part, int nslots, long slot_stride,
-                                                                    float* __restrict__ out, long n_out, int cols, long ld) {
-  const long o = ((long)blockIdx.x * 256 + threadIdx.x) / G;
+__device__ __forceinline__ void wide_sum(const float* __restrict__ part, int nslots, long slot_stride, float* __restrict__ out,
+                                         long n_out, int cols, long ld, long block) {
+  const long o = (block * 256 + threadIdx.x) / G;
   const int g = threadIdx.x % G;
   const bool ok = o < n_out;
   const long r = ok ? o / cols : 0;
@@ -64,29 +64,40 @@ __global__ __launch_bounds__(256) void ordered_finalize_wide_kernel(const float*
   const float* src = part + r * cols + c;
   float t = 0.f;
   if (ok) {
-    int s = g;
-    for (; s + 7 * G < nslots; s += 8 * G) {   // eight loads in flight; the additions stay in slot order
+    for (int s = g; s < nslots; s += 8 * G) {   // eight loads in flight (past the end: + 0); the additions stay in slot order
       float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + (long)(s + j * G) * slot_stride);
+      for (int j = 0; j < 8; ++j) v[j] = s + j * G < nslots ? __builtin_nontemporal_load(src + (long)(s + j * G) * slot_stride) : 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) t += v[j];
     }
-    for (; s < nslots; s += G) t += __builtin_nontemporal_load(src + (long)s * slot_stride);
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
   if (ok && g == 0) out[r * ld + c] += t;
 }
+template <int G>
+__global__ __launch_bounds__(256) void ordered_finalize_wide_kernel(const float* __restrict__ part, int nslots, long slot_stride,
+                                                                    float* __restrict__ out, long n_out, int cols, long ld) {
+  wide_sum<G>(part, nslots, slot_stride, out, n_out, cols, ld, blockIdx.x);
+}
 
 // Mid-sized outputs (a 64 x 576 conv weight gradient over 256 slots: 36 workgroups of the kernel above, every thread a
 // chain of 64 dependent rounds of loads: 21 us): a workgroup owns 256 / SG float4 columns, thread group g adds the slots
 // g, g + SG, ... (eight loads in flight), the groups are combined through LDS in group order.  One association per run.
+// Optional second job (the bias gradient that comes with a Linear's weight gradient: one vector of nb outputs over the same
+// slots, partb / strideb / outb): the blocks past the first job's add it, 16 lanes per output - one launch for both.
 template <int SG>
 __global__ __launch_bounds__(256) void ordered_finalize_grouped_kernel(const float* __restrict__ part, int nslots, long slot_stride,
-                                                                       float* __restrict__ out, long rows, int cols, long ld) {
+                                                                       float* __restrict__ out, long rows, int cols, long ld,
+                                                                       unsigned blocks_a, const float* __restrict__ partb,
+                                                                       long strideb, float* __restrict__ outb, int nb) {
   constexpr int CW = 256 / SG;
   __shared__ float4 red[SG][CW];
+  if (blockIdx.x >= blocks_a) {   // block-uniform
+    wide_sum<16>(partb, nslots, strideb, outb, nb, nb, nb, (long)blockIdx.x - blocks_a);
+    return;
+  }
   const int c = threadIdx.x % CW, g = threadIdx.x / CW;
   const long per_row = cols / 4;
   const long i = (long)blockIdx.x * CW + c;
@@ -162,9 +173,31 @@ int rvit_bn_stats_finalize_impl(const float* part, int nslots, int C, float* sum
 
 int rvit_ordered_finalize(const float* part, int nslots, long slot_stride, float* out, long rows, int cols, long ld,
                           hipStream_t st) {
+  return rvit_ordered_finalize_pair(part, nslots, slot_stride, out, rows, cols, ld, nullptr, 0, nullptr, 0, st);
+}
+
+// ... with a second vector (partb: nslots slots strideb apart, nb outputs) added in the same launch where the first job
+// runs the grouped kernel; two launches otherwise.  Which form runs depends on the shapes only: one association per
+// output for a given reduction, on every run.
+int rvit_ordered_finalize_pair(const float* part, int nslots, long slot_stride, float* out, long rows, int cols, long ld,
+                               const float* partb, long strideb, float* outb, int nb, hipStream_t st) {
   RVIT_CHECK_ARG(part && out && nslots > 0 && rows > 0 && cols > 0 && ld >= cols, "ordered_finalize: bad arguments");
+  RVIT_CHECK_ARG(!partb || (outb && nb > 0 && strideb >= nb), "ordered_finalize: bad second job");
+  if (partb) {
+    const bool vec2 = (cols & 3) == 0 && (ld & 3) == 0 && (slot_stride & 3) == 0 && rvit_aligned16(part) && rvit_aligned16(out);
+    const long n2 = rows * (cols / 4);
+    const long n_out2 = rows * cols;
+    const bool wide_first = (n_out2 <= 16 && nslots >= 64) || (n_out2 <= 4096 && nslots >= 128) || (n_out2 <= 16384 && nslots >= 32);
+    const bool grouped = vec2 && !wide_first && ((nslots >= 32 && n2 <= 16384) || (nslots >= 16 && n2 <= 65536));
+    if (!grouped || nslots < 32) {   // the bias job keeps the kernel a call of its own would run
+      if (const int rc = rvit_ordered_finalize_pair(part, nslots, slot_stride, out, rows, cols, ld, nullptr, 0, nullptr, 0, st)) return rc;
+      return rvit_ordered_finalize_pair(partb, nslots, strideb, outb, 1, nb, nb, nullptr, 0, nullptr, 0, st);
+    }
+  }
   const long n_out = rows * cols;
-  if (n_out <= 16 && nslots >= 64) {
+  // few outputs, many slots (BatchNorm sums from 256-512 conv tiles, LayerNorm affine gradients from 256 workgroups): 64
+  // lanes per output, so that a lane's run of slots is one round of loads
+  if ((n_out <= 16 && nslots >= 64) || (n_out <= 4096 && nslots >= 128)) {
     hipLaunchKernelGGL(ordered_finalize_wide_kernel<64>, dim3((unsigned)((n_out * 64 + 255) / 256)), dim3(256), 0, st, part, nslots,
                        slot_stride, out, n_out, cols, ld);
     RVIT_CHECK_LAUNCH("ordered_finalize");
@@ -179,15 +212,18 @@ int rvit_ordered_finalize(const float* part, int nslots, long slot_stride, float
   const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && (slot_stride & 3) == 0 && rvit_aligned16(part) && rvit_aligned16(out);
   const long n = rows * (vec ? cols / 4 : cols);
   RVIT_CHECK_ARG((n + 255) / 256 < 0x7fffffffL, "ordered_finalize: too many elements");
-  if (vec && nslots >= 32 && n <= 8192) {          // up to 512 workgroups of 16 columns x 16 slot groups
-    hipLaunchKernelGGL(ordered_finalize_grouped_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, nslots, slot_stride,
-                       out, rows, cols, ld);
+  const unsigned blocks_b = partb ? (unsigned)(((long)nb * 16 + 255) / 256) : 0u;
+  if (vec && nslots >= 32 && n <= 16384) {         // up to 1024 workgroups of 16 columns x 16 slot groups
+    const unsigned blocks_a = (unsigned)((n + 15) / 16);
+    hipLaunchKernelGGL(ordered_finalize_grouped_kernel<16>, dim3(blocks_a + blocks_b), dim3(256), 0, st, part, nslots, slot_stride,
+                       out, rows, cols, ld, blocks_a, partb, strideb, outb, nb);
     RVIT_CHECK_LAUNCH("ordered_finalize");
     return RVIT_OK;
   }
   if (vec && nslots >= 16 && n <= 65536) {         // up to 1024 workgroups of 64 columns x 4 slot groups
-    hipLaunchKernelGGL(ordered_finalize_grouped_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, nslots, slot_stride,
-                       out, rows, cols, ld);
+    const unsigned blocks_a = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(ordered_finalize_grouped_kernel<4>, dim3(blocks_a + blocks_b), dim3(256), 0, st, part, nslots, slot_stride,
+                       out, rows, cols, ld, blocks_a, partb, strideb, outb, nb);
     RVIT_CHECK_LAUNCH("ordered_finalize");
     return RVIT_OK;
   }

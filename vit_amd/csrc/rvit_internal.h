@@ -154,6 +154,8 @@ struct WgradArgs {
 
 int rvit_ordered_finalize(const float* part, int nslots, long slot_stride, float* out, long rows, int cols, long ld,
                           hipStream_t st);
+int rvit_ordered_finalize_pair(const float* part, int nslots, long slot_stride, float* out, long rows, int cols, long ld,
+                               const float* partb, long strideb, float* outb, int nb, hipStream_t st);
 int rvit_bn_stats_finalize_impl(const float* part, int nslots, int C, float* sums, float* stage, hipStream_t st);
 int rvit_ordered_splits(long units, long splits, int sub, long elems, size_t ws_bytes, const char* what, long* out);
 

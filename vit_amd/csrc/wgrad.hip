@@ -457,9 +457,11 @@ static int wgrad_ordered_setup(WgradArgs& o, long units, int sub, long* splits) 
 static int wgrad_ordered_finish(const WgradArgs& o, int splits, hipStream_t st) {
   if (!o.part) return RVIT_OK;
   const int nslots = splits * o.part_sub;
-  if (const int rc = rvit_ordered_finalize(o.part, nslots, o.part_stride, o.dW, o.N_store, o.K, o.ldw, st)) return rc;
-  if (o.part_bias) return rvit_ordered_finalize(o.part_bias, nslots, o.N_store, o.dbias, 1, o.N_store, o.N_store, st);
-  return RVIT_OK;
+  // the bias sums ride in the weight gradient's launch where that runs the grouped kernel
+  if (o.part_bias)
+    return rvit_ordered_finalize_pair(o.part, nslots, o.part_stride, o.dW, o.N_store, o.K, o.ldw, o.part_bias, o.N_store, o.dbias,
+                                      o.N_store, st);
+  return rvit_ordered_finalize(o.part, nslots, o.part_stride, o.dW, o.N_store, o.K, o.ldw, st);
 }
 
 int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
