@@ -422,6 +422,8 @@ int rvit_gemm_dispatch(const GemmArgs& a, hipStream_t stream) {
     case 5: return rvit_gemm8p(a, stream);
     case 6: return launch_cfg<256, 128, 8, 2, 2>(a, stream);
     case 7: return launch_cfg<128, 128, 4, 2, 2>(a, stream);
+    // (the same tile with a ring of 3 / 4 stages, one workgroup per CU: 20-31 us against 15.6-22.7 on the N = 768 / 1024
+    // shapes, equal elsewhere: profiles/r03_session2_notes.txt)
     // 64x64 wave tiles (<256,64,4>, <128,64,2>, <512,64,8>: fewer LDS reads per MFMA) measured 20-35 % slower:
     // this loop is latency-bound and wants the 16 waves per CU (profiles/r01_tile_sweep_wave64.txt)
     default: rvit_set_error("gemm: unknown tile config %d", cfg); return RVIT_EINVAL;

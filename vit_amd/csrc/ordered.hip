@@ -63,6 +63,8 @@ __device__ __forceinline__ void wide_sum(const float* __restrict__ part, int nsl
   const int c = ok ? (int)(o - r * cols) : 0;
   const float* src = part + r * cols + c;
   float t = 0.f;
+  float prev = 0.f;   // the value the total is added to, requested with the slots instead of after them
+  if (ok && g == 0) prev = out[r * ld + c];
   if (ok) {
     for (int s = g; s < nslots; s += 8 * G) {   // eight loads in flight (past the end: + 0); the additions stay in slot order
       float v[8];
@@ -74,7 +76,7 @@ __device__ __forceinline__ void wide_sum(const float* __restrict__ part, int nsl
   }
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-  if (ok && g == 0) out[r * ld + c] += t;
+  if (ok && g == 0) out[r * ld + c] = prev + t;
 }
 template <int G>
 __global__ __launch_bounds__(256) void ordered_finalize_wide_kernel(const float* __restrict__ part, int nslots, long slot_stride,
@@ -105,6 +107,8 @@ __global__ __launch_bounds__(256) void ordered_finalize_grouped_kernel(const flo
   const long r = ok ? i / per_row : 0;
   const int col = ok ? (int)(i - r * per_row) * 4 : 0;
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);   // the values the totals are added to, requested with the slots
+  if (g == 0 && ok) o = *reinterpret_cast<const float4*>(out + r * ld + col);
   if (ok) {
     const float* src = part + r * cols + col;
     int s = g;
@@ -126,7 +130,6 @@ __global__ __launch_bounds__(256) void ordered_finalize_grouped_kernel(const flo
 #pragma unroll
     for (int k = 1; k < SG; ++k) { t.x += red[k][c].x; t.y += red[k][c].y; t.z += red[k][c].z; t.w += red[k][c].w; }
     float* dst = out + r * ld + col;
-    float4 o = *reinterpret_cast<float4*>(dst);
     o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
     *reinterpret_cast<float4*>(dst) = o;
   }
