@@ -161,6 +161,7 @@ int rvit_ordered_splits(long units, long splits, int sub, long elems, size_t ws_
 
 int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st);
 bool rvit_conv3x3_wgrad_direct_ok(const WgradArgs& a);            // wgrad3x3.hip
+bool rvit_conv3x3_wgrad_direct_pays(const WgradArgs& a);
 int rvit_conv3x3_wgrad_direct(const WgradArgs& a, hipStream_t st);
 
 int rvit_layernorm_fwd_impl(const void* x, int x_f32, long ldx, const float* gamma, const float* beta, void* y,

@@ -481,7 +481,7 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
   if (a.M == 0) return RVIT_OK;
   // 3x3 / stride 1 convs: LDS-resident patch kernel (wgrad3x3.hip).  splits: 0 = automatic choice, -2 forces it,
   // -1 or an explicit split count keep the implicit-GEMM kernel below (tests compare the two)
-  if (a.splits == -2 || (a.splits == 0 && rvit_conv3x3_wgrad_direct_ok(a))) {
+  if (a.splits == -2 || (a.splits == 0 && rvit_conv3x3_wgrad_direct_ok(a) && rvit_conv3x3_wgrad_direct_pays(a))) {
     WgradArgs d = a;
     d.splits = 0;
     return rvit_conv3x3_wgrad_direct(d, st);
@@ -527,8 +527,10 @@ int rvit_wgrad_dispatch(const WgradArgs& a, hipStream_t st) {
   // ~1024 workgroups (two fit a CU at 64 KB LDS each; two rounds measured best on the stem shapes,
   // profiles/r01_wgrad_splits.txt).  Every split adds N*K atomics, so a split must also own a few M
   // tiles to pay for its epilogue (the encoder Linears: M = B*S is short).
+  // (gather form: AT MOST 1024, whole rounds of two workgroups per CU - 144 tiles x 8 splits = 1152 workgroups ran a
+  // quarter round behind 144 x 7: 136 against 123 us on layer4's 3x3 convs at B = 256)
   const long target = a.mode == 1 ? 1024 : 512;
-  long splits = a.splits > 0 ? a.splits : (target + tiles - 1) / tiles;
+  long splits = a.splits > 0 ? a.splits : a.mode == 1 ? (target >= tiles ? target / tiles : 1) : (target + tiles - 1) / tiles;
   if (a.splits <= 0 && splits > (mtiles + 3) / 4) splits = (mtiles + 3) / 4;
   if (splits > mtiles) splits = mtiles;
   if (splits < 1) splits = 1;

@@ -319,6 +319,14 @@ bool rvit_conv3x3_wgrad_direct_ok(const WgradArgs& a) {
   return w3_patch_pixels(a.H, a.W, tl) <= WD_PMAX;
 }
 
+// Does the direct kernel pay against the implicit-GEMM one?  Not on maps narrower than 14 pixels with >= 64 channel pairs
+// (layer4 of the stem: 512 -> 512 on 7 x 7): its general form recomputes the pixel -> patch map per tile and every pair
+// re-reads its slices; scripts/bench_wgrad3x3.py, B = 64 / 128 / 256 / 512: 57 / 83 / 137 / 247 us direct against
+// 57 / 77 / 123 / 215 for the gather kernel on whole rounds of workgroups.  (Same sums in another order.)
+bool rvit_conv3x3_wgrad_direct_pays(const WgradArgs& a) {
+  return !(a.W < 14 && (long)(a.N / 64) * (a.Cpix / 64) >= 64);
+}
+
 int rvit_conv3x3_wgrad_direct(const WgradArgs& a, hipStream_t st) {
   RVIT_CHECK_ARG(rvit_conv3x3_wgrad_direct_ok(a), "conv3x3 wgrad (direct): unsupported geometry");
   W3Args p;
