@@ -329,9 +329,11 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const bf16* __restri
     }
   }
   __syncthreads();
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const int c8 = C >> 3;
-  if (idx >= (long)B * Ho * Wo * c8) return;
+  const long total = (long)B * Ho * Wo * c8;
+  // grid-stride: a workgroup pays for its table (a dependent chain of loads before the first window) once, not once per
+  // 32 pooled pixels
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
   const int cq = (int)(idx % c8);
   long r = idx / c8;
   const int wo = (int)(r % Wo);
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const bf16* __restri
   a.x = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
   a.y = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
   *reinterpret_cast<uint2*>(argmax + obase) = a;
+  }
 }
 
 // POOL variants of the two backward kernels (the stem's first BatchNorm, whose ReLU output feeds the 3x3 / stride-2
@@ -801,6 +804,38 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* __restrict
 bool bn_shape_ok(long M, int C) { return M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (256 % (C >> 3)) == 0; }  // C/8 a power of two <= 256
 
 // workgroups for M rows when a thread should see about `rows_per_thread` rows; 8 workgroups per CU at most
+static int bn_rpt() { return 8; }
+// Workgroup caps of the two elementwise passes.  On maps that fit the caches a few times over, ONE workgroup of 256
+// threads per CU streaming a long contiguous run of rows beats 6-8 workgroups per CU on short runs (scripts/bench_bn.py,
+// B = 256, us at 2048 / 512 / 256 workgroups: apply layer1 44.5 / 39.6 / 38.7, layer2 39.8 / 26.8 / 24.9, layer3 24.8 / 20.6 /
+// 17.0, layer4 15.3 / 15.4 / 12.8; backward apply layer1 62.9 / 64.5 / 92.2, layer2 44.9 / 35.7 / 38.9, layer3 29.8 / 24.5 /
+// 24.7, layer4 20.3 / 20.2 / 18.2): every thread pays a dependent chain for its per-channel constants before its first
+// row, and fewer, longer streams keep DRAM pages open.  The 411 MB map of the stem entry wants all the workgroups it can
+// get.  RVIT_BN_WG_APPLY / RVIT_BN_WG_BWD override the caps (A/B runs; the results do not depend on the grid).
+static long bn_env_cap(const char* name) {
+  const char* e = getenv(name);
+  const long x = e ? atol(e) : 0;
+  return x > 0 ? x : 0;
+}
+static int bn_num_cu() {
+  static const int v = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  return v;
+}
+static long bn_apply_cap(long M, int C) {
+  static const long env = bn_env_cap("RVIT_BN_WG_APPLY");
+  if (env) return env;
+  return M * C * 2 <= (128L << 20) ? bn_num_cu() : 2048;
+}
+static long bn_bwd_apply_cap(long M, int C) {
+  static const long env = bn_env_cap("RVIT_BN_WG_BWD");
+  if (env) return env;
+  const long bytes = M * C * 2;
+  return bytes <= (16L << 20) ? bn_num_cu() : bytes <= (64L << 20) ? 2L * bn_num_cu() : 2048;
+}
 long bn_blocks(long M, int C, int rows_per_thread) {
   const long per = (long)(256 / (C >> 3)) * rows_per_thread;
   long blocks = (M + per - 1) / per;
@@ -839,7 +874,8 @@ int rvit_bn_apply_impl(const void* y, const float* sums, const float* gamma, con
   RVIT_CHECK_ARG(rvit_aligned16(y) && rvit_aligned16(z) && (!res || rvit_aligned16(res)), "bn_apply: alignment");
   RVIT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_apply: running stats come in pairs");
   RVIT_CHECK_ARG(!relu_mask || relu, "bn_apply: a ReLU mask needs relu");
-  const long blocks = bn_blocks(M, C, 8);
+  long blocks = bn_blocks(M, C, bn_rpt());
+  if (const long cap = bn_apply_cap(M, C); blocks > cap) blocks = cap;
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)y, sums,
                      gamma, beta, (const bf16*)res, (bf16*)z, M, C, eps, relu, momentum, running_mean, running_var,
                      (uint8_t*)relu_mask);
@@ -858,7 +894,13 @@ int rvit_bn_apply_pool_impl(const void* y, const float* sums, const float* gamma
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long total = (long)B * Ho * Wo * (C >> 3);
   RVIT_CHECK_ARG((total + 255) / 256 < 0x7fffffffL, "bn_apply_pool: too many elements");
-  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 2 * C * sizeof(float), st,
+  long pool_blocks = (total + 255) / 256;
+  {
+    static const long env = bn_env_cap("RVIT_BN_WG_POOL");
+    const long cap = env ? env : 16L * bn_num_cu();   // B = 256: 218 us at 25,088 workgroups, 210 at 4,096-8,192, 236 at 2,048
+    if (pool_blocks > cap) pool_blocks = cap;
+  }
+  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)pool_blocks), dim3(256), 2 * C * sizeof(float), st,
                      (const bf16*)y, sums, gamma, beta, (bf16*)pooled, (uint8_t*)argmax, (uint8_t*)relu_mask, B, H, W, C,
                      Ho, Wo, eps, momentum, running_mean, running_var);
   RVIT_CHECK_LAUNCH("bn_apply_pool");
@@ -886,7 +928,8 @@ int rvit_bn_bwd_apply_impl(const void* dz, const void* z, const void* y, const f
   RVIT_CHECK_ARG(rvit_aligned16(dz) && rvit_aligned16(y) && rvit_aligned16(dy) && (relu != 1 || rvit_aligned16(z)) &&
                      (!dzm_out || rvit_aligned16(dzm_out)),
                  "bn_bwd_apply: alignment");
-  const long blocks = bn_blocks(M, C, 8);
+  long blocks = bn_blocks(M, C, bn_rpt());
+  if (const long cap = bn_bwd_apply_cap(M, C); blocks > cap) blocks = cap;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dz,
                      (const bf16*)z, (const bf16*)y, fsums, bsums, gamma, (bf16*)dy, (bf16*)dzm_out, dgamma, dbeta, M,
                      C, eps, relu, PoolGeom{});
@@ -943,13 +986,18 @@ int rvit_bn_bwd_apply_pool_impl(const void* dpool, const void* argmax, const voi
   PoolGeom g;
   if (const int rc = pool_geom(argmax, B, H, W, C, &g, "bn_bwd_apply_pool")) return rc;
   if (!(H & 1) && !(W & 1) && !pool_per_pixel()) {
-    const long MB = M / 4, blocks = bn_blocks(MB, C, 4);
+    const long MB = M / 4;
+    long blocks = bn_blocks(MB, C, 4);
+    {
+      static const long env = bn_env_cap("RVIT_BN_WG_POOLBWD");
+      if (env && blocks > env) blocks = env;
+    }
     hipLaunchKernelGGL(bn_bwd_apply_pool2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dpool,
                        (const uint8_t*)relu_mask, (const bf16*)y, fsums, bsums, gamma, (bf16*)dy, dgamma, dbeta, MB, C, eps, g);
     RVIT_CHECK_LAUNCH("bn_bwd_apply_pool");
     return RVIT_OK;
   }
-  const long blocks = bn_blocks(M, C, 8);
+  const long blocks = bn_blocks(M, C, bn_rpt());
   hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dpool,
                      (const bf16*)relu_mask, (const bf16*)y, fsums, bsums, gamma, (bf16*)dy, (bf16*)nullptr, dgamma, dbeta,
                      M, C, eps, 2, g);
