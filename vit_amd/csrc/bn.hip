@@ -804,6 +804,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* __restrict
 bool bn_shape_ok(long M, int C) { return M > 0 && C >= 8 && C <= 2048 && (C & 7) == 0 && (256 % (C >> 3)) == 0; }  // C/8 a power of two <= 256
 
 // workgroups for M rows when a thread should see about `rows_per_thread` rows; 8 workgroups per CU at most
+static long bn_env_cap(const char* name) {
+  const char* e = getenv(name);
+  const long x = e ? atol(e) : 0;
+  return x > 0 ? x : 0;
+}
 static int bn_rpt() { return 8; }
 // Workgroup caps of the two elementwise passes.  On maps that fit the caches a few times over, ONE workgroup of 256
 // threads per CU streaming a long contiguous run of rows beats 6-8 workgroups per CU on short runs (scripts/bench_bn.py,
@@ -812,11 +817,6 @@ static int bn_rpt() { return 8; }
 // 24.7, layer4 20.3 / 20.2 / 18.2): every thread pays a dependent chain for its per-channel constants before its first
 // row, and fewer, longer streams keep DRAM pages open.  The 411 MB map of the stem entry wants all the workgroups it can
 // get.  RVIT_BN_WG_APPLY / RVIT_BN_WG_BWD override the caps (A/B runs; the results do not depend on the grid).
-static long bn_env_cap(const char* name) {
-  const char* e = getenv(name);
-  const long x = e ? atol(e) : 0;
-  return x > 0 ? x : 0;
-}
 static int bn_num_cu() {
   static const int v = [] {
     int dev = 0, n = 0;
@@ -846,7 +846,11 @@ long red_blocks(long M, int C, bool ordered) {
   const long per = (long)(RED_THREADS / (C >> 3)) * 4;
   long blocks = (M + per - 1) / per;
   // ordered form: the last workgroup reads blocks * 2C partials on its own, so wide maps run fewer workgroups
-  const long cap = !ordered ? 256 : (C <= 128 ? 256 : (C <= 256 ? 128 : 64));
+  long cap = !ordered ? 256 : (C <= 64 ? 256 : (C <= 256 ? 128 : 64));   // (C = 128 at B = 256: 30.7 us at 128 workgroups, 33.2 at 256)
+  {
+    static const long env = bn_env_cap("RVIT_BN_WG_RED");
+    if (env && (!ordered || env * 2 * C <= 262144)) cap = env;
+  }
   return blocks > cap ? cap : blocks;
 }
 size_t red_lds(int C, bool ordered) {
