@@ -190,7 +190,8 @@ int rvit_ordered_finalize_pair(const float* part, int nslots, long slot_stride, 
     const bool vec2 = (cols & 3) == 0 && (ld & 3) == 0 && (slot_stride & 3) == 0 && rvit_aligned16(part) && rvit_aligned16(out);
     const long n2 = rows * (cols / 4);
     const long n_out2 = rows * cols;
-    const bool wide_first = (n_out2 <= 16 && nslots >= 64) || (n_out2 <= 4096 && nslots >= 128) || (n_out2 <= 16384 && nslots >= 32);
+    const bool wide_first = (n_out2 <= 16 && nslots >= 64) || (n_out2 <= 4096 && nslots >= 128) ||
+                            (n_out2 <= 16384 && nslots >= 32 && !(vec2 && n_out2 > 4096));
     const bool grouped = vec2 && !wide_first && ((nslots >= 32 && n2 <= 16384) || (nslots >= 16 && n2 <= 65536));
     if (!grouped || nslots < 32) {   // the bias job keeps the kernel a call of its own would run
       if (const int rc = rvit_ordered_finalize_pair(part, nslots, slot_stride, out, rows, cols, ld, nullptr, 0, nullptr, 0, st)) return rc;
@@ -206,13 +207,15 @@ int rvit_ordered_finalize_pair(const float* part, int nslots, long slot_stride, 
     RVIT_CHECK_LAUNCH("ordered_finalize");
     return RVIT_OK;
   }
-  if (n_out <= 16384 && nslots >= 32) {
+  const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && (slot_stride & 3) == 0 && rvit_aligned16(part) && rvit_aligned16(out);
+  // (above 4096 outputs the float4 grouped kernel below: the stem conv's 64 x 224 weight gradient over 512 slots took 35 us
+  // on scalar loads)
+  if (n_out <= 16384 && nslots >= 32 && !(vec && n_out > 4096)) {
     hipLaunchKernelGGL(ordered_finalize_wide_kernel<16>, dim3((unsigned)((n_out * 16 + 255) / 256)), dim3(256), 0, st, part, nslots,
                        slot_stride, out, n_out, cols, ld);
     RVIT_CHECK_LAUNCH("ordered_finalize");
     return RVIT_OK;
   }
-  const bool vec = (cols & 3) == 0 && (ld & 3) == 0 && (slot_stride & 3) == 0 && rvit_aligned16(part) && rvit_aligned16(out);
   const long n = rows * (vec ? cols / 4 : cols);
   RVIT_CHECK_ARG((n + 255) / 256 < 0x7fffffffL, "ordered_finalize: too many elements");
   const unsigned blocks_b = partb ? (unsigned)(((long)nb * 16 + 255) / 256) : 0u;
