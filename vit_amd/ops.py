@@ -61,13 +61,16 @@ def _nbytes(*ts) -> int:
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _stream() -> int:
     """hipStream_t of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream
-    object through several Python layers (~8 us, ~400 times per training step); the raw getter is one C call."""
+    object through several Python layers (~8 us, ~400 times per training step); the raw getters are two C calls
+    (every caller has CUDA tensors in hand, so the runtime is initialised: torch.cuda.current_device()'s lazy-init
+    check, three Python frames per call, is not needed)."""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_raw_device() if _raw_device is not None else torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
