@@ -505,8 +505,10 @@ class TrainEngine:
                 torch._foreach_add_(self._bn_counters(), 1)
             else:
                 # both directions of the 7x7 conv read the fp32 input itself on the rolling band; otherwise the packed copy
+                # (the weight gradient needs one 64 x 224 slot per image in the ordered workspace: B <= ~3,400 at 192 MB)
                 b["xin"] = xin if (self.conv1_roll and self.conv1_wgrad_roll and self.ordered
-                                   and tuple(xin.shape[1:]) == (3, 224, 224)) else None
+                                   and tuple(xin.shape[1:]) == (3, 224, 224)
+                                   and B * 64 * 224 * 4 <= ops.ORDERED_WORKSPACE_BYTES) else None
                 if b["xin"] is None:
                     ops.input_pack(xin, b["img"], 3, 3)
                 feat = self._stem_forward(P, b, B, xin)
