@@ -112,6 +112,17 @@ def test_small_reductions_ordered(dev, ordered):
         return torch.cat([dg, db])
     u, v = _twice(ln)
     assert torch.equal(u, v)
+
+    def ln_adjacent():   # weight and bias gradients back to back (a flat gradient buffer): one finalisation launch for both
+        dx = torch.zeros(rows, E, device=dev)
+        flat = torch.zeros(2 * E, device=dev)
+        ops.layernorm_bwd(dy, xx, mean, rstd, gamma, dx, flat[:E], flat[E:], accumulate=False)
+        return flat
+    w = ln_adjacent()
+    if ordered:
+        assert torch.equal(u, w)   # same association per output as the two-launch form
+    else:
+        assert torch.allclose(u, w, rtol=1e-4, atol=1e-3)
     xh = (xx - mean[:, None]) * rstd[:, None]
     assert torch.allclose(u[:E], (dy.float() * xh).sum(0), rtol=1e-3, atol=5e-2)
     assert torch.allclose(u[E:], dy.float().sum(0), rtol=1e-3, atol=5e-2)
