@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import torch  # noqa: F401  -- must be imported BEFORE librvit.so is loaded: torch ships its own
 #                              libamdhip64; loading ours first would bring up a second HIP runtime
@@ -112,13 +113,43 @@ SIGNATURES = {
 }
 
 _lib = None
+_tls = threading.local()   # .rec: the CallRecorder standing in for the library on this thread (vit_amd/plan.py)
+
+
+class CallRecorder:
+    """Stands in for the loaded library on ONE thread while a launch plan is recorded (vit_amd/plan.py): every
+    entry point that takes a stream (the launches; the `*_supported` queries and rvit_last_error take none) is
+    appended to `calls` as [function, [arguments], name] and then called as usual."""
+
+    def __init__(self, lib):
+        self._lib = lib
+        self.calls = []
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        sig = SIGNATURES.get(name)
+        if sig is None or not sig[0] or sig[0][-1] is not P:
+            return fn
+        calls = self.calls
+
+        def recorded(*args):
+            calls.append([fn, list(args), name])
+            return fn(*args)
+        return recorded
+
+
+def record_calls(on: bool):
+    """Start (-> the CallRecorder) or stop (-> None) recording this thread's launches."""
+    _tls.rec = CallRecorder(load()) if on else None
+    return _tls.rec
 
 
 def load() -> ctypes.CDLL:
     """Load librvit.so once; raise loudly when it is absent or has the wrong ABI."""
     global _lib
     if _lib is not None:
-        return _lib
+        rec = getattr(_tls, "rec", None)
+        return _lib if rec is None else rec
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"librvit.so not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; "

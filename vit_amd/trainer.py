@@ -20,6 +20,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
+from .plan import run_planned
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -256,6 +257,11 @@ class TrainEngine:
         # BatchNorm backward sums in the epilogue of the dgrad conv that produces the norm's incoming gradient (0: the
         # bn_bwd_reduce pass, A/B runs)
         self.bnr_fused = os.environ.get("RVIT_BN_REDUCE_FUSED", "1") != "0"
+        # the stem's forward and backward passes replayed from recorded launch plans (vit_amd/plan.py; needs the
+        # optimiser-maintained operand copies of vit_amd.optim.FusedAdamW; 0: always through the op wrappers)
+        self.launch_plans = os.environ.get("RVIT_LAUNCH_PLAN", "1") != "0"
+        self._plans: dict = {}
+        self.plan_replays: dict = {}   # pass name -> how often it ran from its plan (tests, bench)
         self.mb = None   # MobileStemTrainer for backbone='mobilenetv3'
         if getattr(model, "backbone_name", None) == "mobilenetv3":
             from .mobile_trainer import MobileStemTrainer
@@ -440,9 +446,48 @@ class TrainEngine:
         ops.bn_apply(y, fs, bn.weight.detach(), bn.bias.detach(), z, eps=bn.eps, relu=relu, residual=residual,
                      momentum=bn.momentum, running_mean=bn.running_mean, running_var=bn.running_var, relu_mask=mask)
 
+    def _stem_tensors(self, cache):
+        """Every parameter and buffer of the stem, re-listed when the model's tensor-slot cache was rebuilt."""
+        have = self.__dict__.get("_stem_tl")
+        if have is None or have[0] is not cache:
+            cb = self.m.cnn_backbone
+            have = (cache, list(cb.parameters()) + list(cb.buffers()))
+            self.__dict__["_stem_tl"] = have
+        return have[1]
+
+    def _plan_key(self, which: str, P, b, extra=()):
+        """Key of a launch plan (vit_amd/plan.py): everything the recorded launches depend on that is not patched.
+        None: no plan for this call."""
+        mir = self.mirror
+        if not self.launch_plans or mir is None or P is not mir.pack or ops._PROF is not None or self.mb is not None:
+            return None, None
+        cache = self.m.__dict__.get("_slots_cache")   # checked slot by slot at the top of this forward (model._run)
+        if cache is None:
+            return None, None
+        dev = b["dev"]
+        stream = ops._stream()
+        ows = ops._ORDERED_WS.get((dev.index, stream))
+        key = (which, id(b), id(mir), id(cache), id(b["scratch"]), len(b["scratch"]), stream,
+               ows.data_ptr() if ows is not None else 0, self._stat_ws(dev).data_ptr(), self.ordered, self.ordered_bn,
+               self.conv1_roll, self.conv1_wgrad_roll, self.bnr_fused, self.fused_pool_bwd, b.get("xin") is None,
+               mir.wt.data_ptr(), mir.bf16.data_ptr(), tuple(t.data_ptr() for t in self._stem_tensors(cache)), extra)
+        return key, (b, mir, cache, b["scratch"])
+
     def _stem_forward(self, P, b, B, xin=None) -> torch.Tensor:
-        cb = self.m.cnn_backbone
         b["fsums"].zero_()
+        roll = self.conv1_roll and xin is not None and tuple(xin.shape[1:]) == (3, 224, 224)
+        key, refs = self._plan_key("stem_forward", P, b, (roll, tuple(xin.shape) if xin is not None else None))
+        ranges = {"xin": (xin.data_ptr(), xin.numel() * 4)} if xin is not None else {}
+        cur = run_planned(self._plans, "stem_forward", key, refs, ranges,
+                          lambda: self._stem_forward_launches(P, b, B, xin), self.plan_replays)
+        # BatchNorm2d.num_batches_tracked += 1 for every norm of the stem (timm BatchNorm2d in train()): one fused launch
+        # instead of twenty
+        torch._foreach_add_(self._bn_counters(), 1)
+        return cur
+
+    def _stem_forward_launches(self, P, b, B, xin=None) -> torch.Tensor:
+        """C-ABI launches and views only: this pass is recorded and replayed (vit_amd/plan.py)."""
+        cb = self.m.cnn_backbone
         off = 0
         fs = b["fsums"]
         ws = b["bn_ws"] if self.ordered_bn else None
@@ -475,9 +520,6 @@ class TrainEngine:
                           relu=True, residual=idn, mask=d["mo"], ws=ws)
             off += 2 * co * (2 if "ds_w" in pk else 1)
             cur = d["zo"]
-        # BatchNorm2d.num_batches_tracked += 1 for every norm of the stem (timm BatchNorm2d in train()): one fused launch
-        # instead of twenty
-        torch._foreach_add_(self._bn_counters(), 1)
         return cur
 
     def forward(self, x: torch.Tensor, features_only: bool) -> torch.Tensor:
@@ -559,8 +601,24 @@ class TrainEngine:
         return self._g(flat, name).view(rows, -1)
 
     def _stem_backward(self, P, b, B, flat, dfeat: torch.Tensor) -> None:
-        cb = self.m.cnn_backbone
         b["bsums"].zero_()
+        dw1 = b["scratch"].get("dw1")
+        if dw1 is None:
+            dw1 = b["scratch"]["dw1"] = torch.empty(64, 224, dtype=F32, device=dfeat.device)
+        dw1.zero_()
+        key, refs = (None, None)
+        if self.reducer is None:   # the data-parallel exchange is issued between the blocks: not a fixed launch list
+            key, refs = self._plan_key("stem_backward", P, b, (dfeat.data_ptr(), flat.numel()))
+        ranges = {"flat": (flat.data_ptr(), flat.numel() * 4)}
+        if b.get("xin") is not None:
+            ranges["xin"] = (b["xin"].data_ptr(), b["xin"].numel() * 4)
+        run_planned(self._plans, "stem_backward", key, refs, ranges,
+                    lambda: self._stem_backward_launches(P, b, B, flat, dfeat, dw1), self.plan_replays)
+        self._g(flat, "cnn_backbone.conv1.weight").view(64, 7, 7, 3).copy_(dw1.view(64, 7, 8, 4)[:, :, :7, :3])
+
+    def _stem_backward_launches(self, P, b, B, flat, dfeat: torch.Tensor, dw1: torch.Tensor) -> None:
+        """C-ABI launches and views only: this pass is recorded and replayed (vit_amd/plan.py)."""
+        cb = self.m.cnn_backbone
         bs_all, fs_all = b["bsums"], b["fsums"]
         ws = b["bn_ws"] if self.ordered_bn else None
         dz = dfeat
@@ -645,12 +703,10 @@ class TrainEngine:
             ops.bn_bwd(dc1, None, b["c1_y"], fs_all[0:128], bs_all[0:128], cb.bn1.weight.detach(), dyc,
                        self._g(flat, "cnn_backbone.bn1.weight"), self._g(flat, "cnn_backbone.bn1.bias"), eps=cb.bn1.eps,
                        relu=True, relu_mask=b["c1_m"], workspace=ws)
-        dw1 = torch.zeros(64, 224, dtype=F32, device=dyc.device)
         if b.get("xin") is not None:
             ops.stem_conv1_wgrad_f32(dyc, b["xin"], dw1)
         else:
             ops.conv2d_wgrad(dyc, b["img"], dw1, kh=7, kw=1, stride=2, pad=0, seg_len=32)
-        self._g(flat, "cnn_backbone.conv1.weight").view(64, 7, 7, 3).copy_(dw1.view(64, 7, 8, 4)[:, :, :7, :3])
 
     def _block_names(self):
         cb = self.m.cnn_backbone
