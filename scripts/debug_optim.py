@@ -1,3 +1,5 @@
+"""Developer aid: FusedAdamW against torch.optim.AdamW tensor by tensor over a few steps (which tensors differ most, and why:
+the measurement behind the tolerance comment in tests/test_optim_gpu.py)."""
 import sys, torch
 sys.path.insert(0, ".")
 from vit_amd.loss import CrossEntropyLoss
