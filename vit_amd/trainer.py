@@ -461,7 +461,9 @@ class TrainEngine:
         mir = self.mirror
         if not self.launch_plans or mir is None or P is not mir.pack or ops._PROF is not None or self.mb is not None:
             return None, None
-        cache = self.m.__dict__.get("_slots_cache")   # checked slot by slot at the top of this forward (model._run)
+        if which == "stem_forward":
+            self.m._tensor_slots()   # every module slot still holds the tensor object the lists were built from (~15 us)
+        cache = self.m.__dict__.get("_slots_cache")
         if cache is None:
             return None, None
         dev = b["dev"]
