@@ -6,7 +6,7 @@ of the plan: a stale pointer, a missed launch, a missed patch of the input or gr
 The schedules below move everything a plan must notice or patch: a fresh input tensor at a fresh address on every
 step (earlier batches are kept alive), batch-size changes and returns (new buffer sets), a frozen and unfrozen
 backbone (train_vit.py:310-318), an evaluation forward in between, parameters edited behind the optimiser's back
-(load_state_dict), the profiler switched on for a step.
+(load_state_dict), the profiler switched on for a step, a BatchNorm momentum / eps changed by hand.
 """
 import pytest
 import torch
@@ -49,6 +49,9 @@ def _run(dev, backbone, schedule, plans: bool):
                     p.mul_(0.999)
         elif what == "profile":
             ops.set_profiler([])
+        elif what == "momentum":   # a scalar that is baked into the recorded arguments
+            m.cnn_backbone.bn1.momentum = 0.3
+            m.cnn_backbone.layer3["0"].bn2.eps = 2e-5
         x = micro_doppler_batch(B, seed=100 + i).to(dev)
         y = torch.randint(0, 11, (B,), generator=torch.Generator().manual_seed(i)).to(dev)
         keep.append(x)        # the next batch cannot land on this one's address
@@ -69,7 +72,7 @@ SCHEDULES = {
     "batch-changes": [(6, None)] * 5 + [(4, None)] * 5 + [(6, None)] * 5,
     "freeze-unfreeze": [(5, None)] * 4 + [(5, "freeze")] + [(5, None)] * 4 + [(5, "unfreeze")] + [(5, None)] * 5,
     "eval-reload-profile": [(6, None)] * 5 + [(6, "eval")] + [(6, None)] * 2 + [(6, "reload")] + [(6, None)] * 4
-                           + [(6, "profile")] + [(6, None)] * 2,
+                           + [(6, "profile")] + [(6, None)] * 2 + [(6, "momentum")] + [(6, None)] * 4,
 }
 
 

@@ -423,12 +423,15 @@ class TrainEngine:
     def _bn_params(self, bn):
         return bn.weight.detach(), bn.bias.detach()
 
-    def _bn_counters(self):
+    def _bn_modules(self):
         mods = self.__dict__.get("_bn_mods")
         if mods is None:
             mods = [mod for mod in self.m.cnn_backbone.modules() if hasattr(mod, "num_batches_tracked")]
             self.__dict__["_bn_mods"] = mods
-        return [mod.num_batches_tracked for mod in mods]   # looked up per step: .to() replaces the buffers
+        return mods
+
+    def _bn_counters(self):
+        return [mod.num_batches_tracked for mod in self._bn_modules()]   # looked up per step: .to() replaces the buffers
 
     def _stat_ws(self, dev):
         ws = self.__dict__.get("_stat_ws_buf")
@@ -472,7 +475,8 @@ class TrainEngine:
         key = (which, id(b), id(mir), id(cache), id(b["scratch"]), len(b["scratch"]), stream,
                ows.data_ptr() if ows is not None else 0, self._stat_ws(dev).data_ptr(), self.ordered, self.ordered_bn,
                self.conv1_roll, self.conv1_wgrad_roll, self.bnr_fused, self.fused_pool_bwd, b.get("xin") is None,
-               mir.wt.data_ptr(), mir.bf16.data_ptr(), tuple(t.data_ptr() for t in self._stem_tensors(cache)), extra)
+               mir.wt.data_ptr(), mir.bf16.data_ptr(), tuple(t.data_ptr() for t in self._stem_tensors(cache)),
+               tuple((bn.eps, bn.momentum) for bn in self._bn_modules()), extra)
         return key, (b, mir, cache, b["scratch"])
 
     def _stem_forward(self, P, b, B, xin=None) -> torch.Tensor:
