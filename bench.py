@@ -250,6 +250,7 @@ def train_leg(args, dev, dist, world, rank, sd, cfg=None, fwd_flops=FWD_FLOPS_PE
     return {"metric": "train_samples_per_sec", "cpu_baseline": cpu_res, "value": round(sps, 1), "unit": "samples/s",
             "ms_per_step": round(dt / n_steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_host / n_steps * 1e3, 3), "steps": n_steps, "warmup": 3,
+            "launch_plan_replays": dict(getattr(model.train_engine, "plan_replays", {})),   # vit_amd/plan.py
             "dtype": "bf16", "roofline": roof, "kernel_families": split,
             "batch_per_gpu": B,
             "global_batch": world * B, "dropout": cfg["dropout"], "final_loss": round(float(loss.detach()), 4),
